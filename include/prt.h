@@ -1,0 +1,142 @@
+/* prt.h — C-ABI of the MI355X ray-tracing path (libprt_hip.so).
+ *
+ * Drop-in boundary: the reference's class VkRTX (/root/reference/src/vkRTX_setup.h:17-195), owned by
+ * vkContext (/root/reference/src/vkContext.h:147). Every entry point below names the VkRTX member (or
+ * the shader / driver call) it replaces. Plain pointers and sizes only; no exceptions cross the ABI:
+ * every function returns 0 on success or a negative PRT_E_* code, and prt_last_error() gives the text
+ * (the reference throws std::runtime_error from VK_CHECK_RESULT, src/vkTools.h:88-98).
+ *
+ * A context is bound to one GPU and is not thread-safe (the reference renders from a single thread on
+ * a single VkQueue). All calls are asynchronous on the context's HIP stream unless noted.
+ */
+#ifndef PRT_H
+#define PRT_H
+
+#include "prt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct prt_context prt_context;
+
+#define PRT_OK 0
+#define PRT_E_INVALID (-1)  /* bad argument / call order */
+#define PRT_E_HIP (-2)      /* a HIP runtime call failed */
+#define PRT_E_NOSCENE (-3)  /* scene or acceleration structure missing */
+#define PRT_E_LIMIT (-4)    /* input exceeds a documented limit */
+
+/* rendering modes — vkContext.h:184-185, selected in VkRTX::recordCommandBuffer (vkRTX_setup.cpp:721-764) */
+#define PRT_MODE_PATH 0 /* shaders/pathRT.rgen */
+#define PRT_MODE_AO 1   /* shaders/AO.rgen */
+
+/* prt_set_flags */
+#define PRT_FLAG_LITERAL 1u /* reference image semantics: E is reset when ubo.iteration <= 1 (pathRT.rgen:649-654)
+                               and a primary miss OVERWRITES the pixel (pathRT.rgen:693-697). Default (0) is the
+                               additive form needed for multi-GPU sums: E always accumulates, clear with
+                               prt_clear_accum(). */
+#define PRT_FLAG_RUSSIAN_ROULETTE 2u /* extension, not in the reference: off by default */
+
+/* 32-byte node of the build tree, as returned by prt_read_bvh: count == 0 -> inner node with children
+ * nodes[first], nodes[first+1]; count > 0 -> leaf over order[first .. first+count). */
+typedef struct prt_bvh_node
+{
+    float    bmin[3];
+    uint32_t first;
+    float    bmax[3];
+    uint32_t count;
+} prt_bvh_node;
+
+typedef struct prt_ray
+{
+    float o[3];
+    float tmin;
+    float d[3]; /* not normalised: t is in units of |d| (traceNV semantics) */
+    float tmax;
+} prt_ray;
+
+typedef struct prt_hit
+{
+    uint32_t prim; /* gl_PrimitiveID, 0xffffffff on miss (pathRT.rmiss:17-20) */
+    float    u, v; /* hitAttributeNV.xy (pathRT.rchit:19) */
+    float    t;
+} prt_hit;
+
+typedef struct prt_stats
+{
+    uint64_t rays;            /* primary + bounce + shadow/AO rays traced since the last prt_reset_stats */
+    uint64_t iterations;      /* prt_render_iteration equivalents executed */
+    uint32_t bvh_nodes;       /* build-tree nodes */
+    uint32_t bvh_inner_nodes; /* 64-byte traversal nodes */
+    uint32_t bvh_depth;
+    float    bvh_build_ms;    /* wall time of the last prt_build_accel */
+} prt_stats;
+
+/* VkRTX::VkRTX(ctx, extent) — vkRTX_setup.h:20-24. Binds to HIP device `device_ordinal`. */
+int prt_create(int device_ordinal, uint32_t width, uint32_t height, prt_context** out);
+/* VkRTX::cleanUp — vkRTX_setup.h:40, vkRTX_setup.cpp:913-1032 */
+int prt_destroy(prt_context* ctx);
+/* Text of the last error on this context (ctx may be NULL: last error of prt_create). */
+const char* prt_last_error(const prt_context* ctx);
+
+/* VkRTX::initRaytracing(gpu, models, ubo, uboMem) — vkRTX_setup.h:26-29; uses models[0] only
+ * (vkRTX_setup.cpp:67-75, 459, 581-624). Host arrays are copied; the caller keeps ownership. */
+int prt_set_scene(prt_context* ctx, const prt_vertex* vertices, size_t n_vertices, const uint32_t* indices,
+                  size_t n_indices, const prt_material* materials, size_t n_materials, const prt_texture* textures,
+                  size_t n_textures);
+/* createAccelerationStructures (vkRTX_setup.cpp:391-415) -> vkCmdBuildAccelerationStructureNV
+ * (vkRT_BLAS.cpp:271, vkRT_TLAS.cpp:262): binned-SAH BVH build on the GPU. Synchronous. */
+int prt_build_accel(prt_context* ctx);
+
+/* generateNewScrambles + updateScrambleValueImage — vkRTX_setup.h:38-39, vkRTX_setup.cpp:808-911.
+ * Seeded, stateless per (pixel, layer) hash evaluated in the kernels (default seed 1) ... */
+int prt_set_scramble_seed(prt_context* ctx, uint32_t seed);
+/* ... or the reference's explicit table: n_layers (= 32) x width*height u32, layer-major. Copied. */
+int prt_upload_scrambles(prt_context* ctx, const uint32_t* layers, uint32_t n_layers);
+
+/* The host-mapped UBO that vkContext memcpy's every frame — vkContext.cpp:1057-1059. */
+int prt_set_uniforms(prt_context* ctx, const prt_uniforms* ubo);
+int prt_set_flags(prt_context* ctx, uint32_t flags);
+
+/* VkRTX::recordCommandBuffer(cmd, rp, fb, img, mode) — vkRTX_setup.h:32-36: one vkCmdTraceRaysNV(W,H,1)
+ * with the current uniforms == one progressive iteration for all pixels. */
+int prt_render_iteration(prt_context* ctx, int mode);
+/* Convenience: iterations first_iter, first_iter+stride, ... (n_iter of them); ubo.iteration is
+ * overwritten for each. stride > 1 is the multi-GPU sample sharding (rank r renders first_iter = 1+r,
+ * stride = world size). */
+int prt_render(prt_context* ctx, int mode, uint32_t first_iter, uint32_t n_iter, uint32_t iter_stride);
+/* vkQueueWaitIdle — vkTools.cpp:212 */
+int prt_sync(prt_context* ctx);
+
+/* m_rtRenderTarget (vkRTX_setup.h:186-194; RGBA16F there, float4 here): W*H float4, row-major,
+ * pixel (x,y) at y*W+x == gl_LaunchIDNV.xy; the image pathRTpostprocess.comp binding 1 reads. */
+int prt_clear_accum(prt_context* ctx);
+int prt_read_accum(prt_context* ctx, float* rgba_out); /* synchronous */
+int prt_device_accum_ptr(prt_context* ctx, void** dev_ptr);
+/* Render into caller-owned device memory (W*H*16 bytes, 16-byte aligned), e.g. a buffer that an RCCL
+ * all-reduce will sum; NULL returns to the context's own buffer. */
+int prt_bind_accum(prt_context* ctx, void* dev_ptr);
+/* pathRTpostprocess.comp:38-51 over the full image -> RGBA8. Synchronous. */
+int prt_postprocess(prt_context* ctx, uint8_t* rgba8_out);
+
+/* Primary-ray primitive ids of the last iteration (payload.primitiveID after pathRT.rgen:692). Synchronous. */
+int prt_read_hit_ids(prt_context* ctx, uint32_t* ids_out);
+int prt_get_stats(prt_context* ctx, prt_stats* out); /* synchronous */
+int prt_reset_stats(prt_context* ctx);
+
+/* traceNV for a batch of host rays (closest hit, or any_hit != 0 for the terminate-on-first-hit
+ * occlusion query of pathRT.rgen:819-822). Synchronous; for tests and ray-level measurements. */
+int prt_trace(prt_context* ctx, const prt_ray* rays, size_t n, int any_hit, prt_hit* hits_out);
+/* Same on device-resident rays/hits (2 x float4 per ray, 1 x float4 per hit), timed with HIP events on
+ * the context's stream; *ms_out receives the kernel time. */
+int prt_trace_device(prt_context* ctx, const void* rays_dev, size_t n, int any_hit, void* hits_dev, float* ms_out);
+
+/* Inspection of the acceleration structure (nodes_out: bvh_nodes entries, order_out: one per triangle). */
+int prt_read_bvh(prt_context* ctx, prt_bvh_node* nodes_out, uint32_t* order_out);
+/* The 64 x 32 Sobol matrix words in use (sobol.h:28-33 restricted to what the path reads). */
+int prt_read_sobol(prt_context* ctx, uint32_t* words_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRT_H */

@@ -1,0 +1,751 @@
+// prt_api.hip — libprt_hip.so: the C-ABI of include/prt.h over the HIP kernels (gfx950).
+// Host side of what VkRTX does in the reference (src/vkRTX_setup.{h,cpp}): owns the device copies of
+// the scene, the acceleration structure, the Sobol table, the per-path state and the accumulation
+// image, and issues one fixed sequence of kernel launches per iteration on one HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/prt.h"
+#include "prt_bvh.hpp"
+#include "prt_kernels.hpp"
+#include "sobol_table.hpp"
+
+using namespace prt;
+
+static std::string g_createError;
+
+struct prt_context
+{
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t    w = 0, h = 0, npix = 0;
+    uint32_t    flags = 0, seed = 1;
+    int         numCU = 256;
+    std::string err;
+
+    // scene
+    prt_vertex*   dVerts = nullptr;
+    uint32_t*     dIdx   = nullptr;
+    prt_material* dMats  = nullptr;
+    TexDesc*      dTex   = nullptr;
+    std::vector<void*> texMem;
+    uint32_t      nverts = 0, ntri = 0, nmats = 0, ntex = 0;
+    bool          haveScene = false, haveAccel = false;
+
+    // acceleration structure
+    BuildNode* dBuildNodes = nullptr;
+    uint32_t*  dOrder      = nullptr;
+    Node64*    dNodes      = nullptr;
+    float4*    dTris       = nullptr;
+    uint32_t   nNodes = 0, nInner = 0, depth = 0;
+    int32_t    root     = 0;
+    float      sceneAbs = 0.0f, buildMs = 0.0f;
+
+    // sampling
+    uint32_t* dSobol    = nullptr;
+    uint32_t* dScramble = nullptr;
+
+    // frame
+    prt_uniforms  ubo{};
+    prt_uniforms* dUbo = nullptr;  // ring of device copies, one per in-flight iteration
+    prt_uniforms* hUbo = nullptr;  // pinned staging ring
+    uint32_t      uboSlot = 0;
+    float4 *      accumOwn = nullptr, *accum = nullptr;
+    float4 *      rayO = nullptr, *rayD = nullptr, *hit = nullptr, *thr = nullptr, *shO = nullptr, *shD = nullptr,
+           *eiVis = nullptr, *eiOcc = nullptr;
+    float2*             aaOff  = nullptr;
+    uint32_t*           hitIds = nullptr;
+    uint8_t*            dead   = nullptr;
+    uint32_t *          q[2] = {nullptr, nullptr}, *qShadow = nullptr;
+    uint32_t*           counters = nullptr;  // kCounterWords per pass
+    unsigned long long* stats    = nullptr;
+    uint64_t            iterations = 0;
+};
+
+static constexpr uint32_t kUboRing      = 64;
+static constexpr uint32_t kCounterWords = 256;
+static constexpr uint32_t kMaxBounces   = 24;  // UI cap is 10 (vkContext.cpp:266)
+
+static int fail(prt_context* c, int code, const char* fmt, ...)
+{
+    char    buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if(c)
+        c->err = buf;
+    else
+        g_createError = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                            \
+    do                                                                                             \
+    {                                                                                              \
+        hipError_t e_ = (expr);                                                                    \
+        if(e_ != hipSuccess)                                                                       \
+            return fail(c, PRT_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while(0)
+
+template <class T>
+static hipError_t dalloc(T*& p, size_t n)
+{
+    return hipMalloc((void**)&p, n * sizeof(T) > 0 ? n * sizeof(T) : 16);
+}
+template <class T>
+static void dfree(T*& p)
+{
+    if(p) (void)hipFree(p);
+    p = nullptr;
+}
+static inline uint32_t cdiv(size_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+static void free_scene(prt_context* c)
+{
+    dfree(c->dVerts);
+    dfree(c->dIdx);
+    dfree(c->dMats);
+    dfree(c->dTex);
+    for(void* p : c->texMem) (void)hipFree(p);
+    c->texMem.clear();
+    dfree(c->dBuildNodes);
+    dfree(c->dOrder);
+    dfree(c->dNodes);
+    dfree(c->dTris);
+    c->haveScene = c->haveAccel = false;
+}
+
+extern "C" {
+
+const char* prt_last_error(const prt_context* c) { return c ? c->err.c_str() : g_createError.c_str(); }
+
+int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
+{
+    if(!out || width == 0 || height == 0) return fail(nullptr, PRT_E_INVALID, "prt_create: bad arguments");
+    if((uint64_t)width * height >= (1ull << 27))
+        return fail(nullptr, PRT_E_LIMIT, "prt_create: more than 2^27 pixels");
+    int ndev = 0;
+    if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, PRT_E_HIP, "prt_create: no HIP device available (the MI355X path has no CPU fallback)");
+    if(device < 0 || device >= ndev) return fail(nullptr, PRT_E_INVALID, "prt_create: device %d of %d", device, ndev);
+    prt_context* c = new prt_context();
+    c->device      = device;
+    c->w           = width;
+    c->h           = height;
+    c->npix        = width * height;
+    hipError_t e   = hipSetDevice(device);
+    if(e == hipSuccess) e = hipStreamCreate(&c->stream);
+    hipDeviceProp_t prop;
+    if(e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if(e == hipSuccess) c->numCU = prop.multiProcessorCount;
+    const size_t n = c->npix;
+    if(e == hipSuccess) e = dalloc(c->accumOwn, n);
+    if(e == hipSuccess) e = dalloc(c->rayO, n);
+    if(e == hipSuccess) e = dalloc(c->rayD, n);
+    if(e == hipSuccess) e = dalloc(c->hit, n);
+    if(e == hipSuccess) e = dalloc(c->thr, n);
+    if(e == hipSuccess) e = dalloc(c->shO, n);
+    if(e == hipSuccess) e = dalloc(c->shD, n);
+    if(e == hipSuccess) e = dalloc(c->eiVis, n);
+    if(e == hipSuccess) e = dalloc(c->eiOcc, n);
+    if(e == hipSuccess) e = dalloc(c->aaOff, n);
+    if(e == hipSuccess) e = dalloc(c->hitIds, n);
+    if(e == hipSuccess) e = dalloc(c->dead, n);
+    if(e == hipSuccess) e = dalloc(c->q[0], n);
+    if(e == hipSuccess) e = dalloc(c->q[1], n);
+    if(e == hipSuccess) e = dalloc(c->qShadow, n);
+    if(e == hipSuccess) e = dalloc(c->counters, (size_t)kCounterWords);
+    if(e == hipSuccess) e = dalloc(c->stats, (size_t)4);
+    if(e == hipSuccess) e = dalloc(c->dUbo, (size_t)kUboRing);
+    if(e == hipSuccess) e = hipHostMalloc((void**)&c->hUbo, kUboRing * sizeof(prt_uniforms), hipHostMallocDefault);
+    if(e == hipSuccess) e = dalloc(c->dSobol, (size_t)64 * 32);
+    if(e == hipSuccess)
+    {
+        uint32_t tbl[64 * 32];
+        build_sobol_matrices(tbl);
+        e = hipMemcpy(c->dSobol, tbl, sizeof tbl, hipMemcpyHostToDevice);
+    }
+    if(e == hipSuccess) e = hipMemset(c->accumOwn, 0, n * sizeof(float4));
+    if(e == hipSuccess) e = hipMemset(c->stats, 0, 4 * sizeof(unsigned long long));
+    if(e == hipSuccess) e = hipMemset(c->dead, 0, n);
+    if(e == hipSuccess) e = hipMemset(c->hitIds, 0xff, n * 4);
+    if(e != hipSuccess)
+    {
+        fail(nullptr, PRT_E_HIP, "prt_create: %s", hipGetErrorString(e));
+        prt_destroy(c);
+        return PRT_E_HIP;
+    }
+    c->accum = c->accumOwn;
+    // default uniforms = vkContext.h:54-82 defaults
+    memset(&c->ubo, 0, sizeof c->ubo);
+    c->ubo.numIndirectBounces = 4;
+    c->ubo.samplesPerPixel    = 1;
+    c->ubo.numAArays          = 1;
+    c->ubo.filterRadius       = 1.0f;
+    c->ubo.numAOrays          = 16;
+    c->ubo.aoRayLength        = 1.0f;
+    *out = c;
+    return PRT_OK;
+}
+
+int prt_destroy(prt_context* c)
+{
+    if(!c) return PRT_OK;
+    (void)hipSetDevice(c->device);
+    if(c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    dfree(c->accumOwn);
+    dfree(c->rayO);
+    dfree(c->rayD);
+    dfree(c->hit);
+    dfree(c->thr);
+    dfree(c->shO);
+    dfree(c->shD);
+    dfree(c->eiVis);
+    dfree(c->eiOcc);
+    dfree(c->aaOff);
+    dfree(c->hitIds);
+    dfree(c->dead);
+    dfree(c->q[0]);
+    dfree(c->q[1]);
+    dfree(c->qShadow);
+    dfree(c->counters);
+    dfree(c->stats);
+    dfree(c->dUbo);
+    if(c->hUbo) (void)hipHostFree(c->hUbo);
+    dfree(c->dSobol);
+    dfree(c->dScramble);
+    if(c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PRT_OK;
+}
+
+int prt_set_scene(prt_context* c, const prt_vertex* v, size_t nv, const uint32_t* idx, size_t nidx,
+                  const prt_material* m, size_t nm, const prt_texture* tex, size_t ntex)
+{
+    if(!c) return PRT_E_INVALID;
+    if(!v || !idx || !m || nv == 0 || nidx < 3 || nm == 0 || (ntex && !tex))
+        return fail(c, PRT_E_INVALID, "prt_set_scene: empty vertex/index/material input");
+    if(nidx / 3 >= (1u << 28)) return fail(c, PRT_E_LIMIT, "prt_set_scene: more than 2^28 triangles");
+    for(size_t i = 0; i < (nidx / 3) * 3; ++i)
+        if(idx[i] >= nv) return fail(c, PRT_E_INVALID, "prt_set_scene: index %zu (= %u) out of range", i, idx[i]);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    c->nverts = (uint32_t)nv;
+    c->ntri   = (uint32_t)(nidx / 3);
+    c->nmats  = (uint32_t)nm;
+    c->ntex   = (uint32_t)ntex;
+    HIPCHK(c, dalloc(c->dVerts, nv));
+    HIPCHK(c, dalloc(c->dIdx, (size_t)c->ntri * 3));
+    HIPCHK(c, dalloc(c->dMats, nm));
+    HIPCHK(c, hipMemcpy(c->dVerts, v, nv * sizeof(prt_vertex), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dIdx, idx, (size_t)c->ntri * 12, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dMats, m, nm * sizeof(prt_material), hipMemcpyHostToDevice));
+    std::vector<TexDesc> td(ntex);
+    for(size_t i = 0; i < ntex; ++i)
+    {
+        if(!tex[i].rgba || tex[i].width == 0 || tex[i].height == 0)
+            return fail(c, PRT_E_INVALID, "prt_set_scene: texture %zu is empty", i);
+        const size_t bytes = (size_t)tex[i].width * tex[i].height * 4;
+        void*        p     = nullptr;
+        HIPCHK(c, hipMalloc(&p, bytes));
+        c->texMem.push_back(p);
+        HIPCHK(c, hipMemcpy(p, tex[i].rgba, bytes, hipMemcpyHostToDevice));
+        td[i].rgba = (const uint8_t*)p;
+        td[i].w    = tex[i].width;
+        td[i].h    = tex[i].height;
+    }
+    HIPCHK(c, dalloc(c->dTex, ntex));
+    if(ntex) HIPCHK(c, hipMemcpy(c->dTex, td.data(), ntex * sizeof(TexDesc), hipMemcpyHostToDevice));
+    c->haveScene = true;
+    return PRT_OK;
+}
+
+static int device_scan(prt_context* c, uint32_t* data, uint32_t n, uint32_t* tileSums, uint32_t* totalDev)
+{
+    const uint32_t tiles = cdiv(n, PRT_SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(PRT_SCAN_BLOCK), 0, c->stream, data, n, tileSums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(PRT_SCAN_BLOCK), 0, c->stream, tileSums, tiles, totalDev);
+    hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(PRT_SCAN_BLOCK), 0, c->stream, data, n, tileSums);
+    HIPCHK(c, hipGetLastError());
+    return PRT_OK;
+}
+
+int prt_build_accel(prt_context* c)
+{
+    if(!c) return PRT_E_INVALID;
+    if(!c->haveScene) return fail(c, PRT_E_NOSCENE, "prt_build_accel: no scene");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const auto     t0 = std::chrono::steady_clock::now();
+    const uint32_t N  = c->ntri;
+    hipStream_t    st = c->stream;
+    dfree(c->dBuildNodes);
+    dfree(c->dOrder);
+    dfree(c->dNodes);
+    dfree(c->dTris);
+    c->haveAccel = false;
+
+    const uint32_t maxSplit = N / (kLeafMax + 1) + 1;
+    uint32_t *     order2 = nullptr, *nodeOf = nullptr, *nodeOf2 = nullptr, *cb = nullptr, *bins = nullptr;
+    uint32_t *     flags = nullptr, *scanBuf = nullptr, *tileSums = nullptr, *rank = nullptr, *splitOf = nullptr;
+    uint32_t*      total = nullptr;
+    float4*        pbox  = nullptr;
+    SplitRec*      splits = nullptr;
+    int            rc     = PRT_OK;
+    auto           cleanup = [&]() {
+        dfree(order2); dfree(nodeOf); dfree(nodeOf2); dfree(cb); dfree(bins); dfree(flags); dfree(scanBuf);
+        dfree(tileSums); dfree(rank); dfree(splitOf); dfree(total); dfree(pbox); dfree(splits);
+    };
+#define BCHK(expr)                                                                                        \
+    do                                                                                                    \
+    {                                                                                                     \
+        hipError_t e_ = (expr);                                                                           \
+        if(e_ != hipSuccess)                                                                              \
+        {                                                                                                 \
+            cleanup();                                                                                    \
+            return fail(c, PRT_E_HIP, "prt_build_accel: %s failed: %s", #expr, hipGetErrorString(e_));    \
+        }                                                                                                 \
+    } while(0)
+    BCHK(dalloc(c->dBuildNodes, (size_t)2 * N));
+    BCHK(dalloc(c->dOrder, (size_t)N));
+    BCHK(dalloc(order2, (size_t)N));
+    BCHK(dalloc(nodeOf, (size_t)N));
+    BCHK(dalloc(nodeOf2, (size_t)N));
+    BCHK(dalloc(cb, (size_t)12 * N));
+    BCHK(dalloc(bins, (size_t)maxSplit * kBinWords));
+    BCHK(dalloc(flags, (size_t)2 * N));
+    BCHK(dalloc(scanBuf, (size_t)2 * N));
+    BCHK(dalloc(tileSums, (size_t)cdiv((size_t)2 * N, PRT_SCAN_TILE) + 1));
+    BCHK(dalloc(rank, (size_t)N));
+    BCHK(dalloc(splitOf, (size_t)N));
+    BCHK(dalloc(total, (size_t)1));
+    BCHK(dalloc(pbox, (size_t)2 * N));
+    BCHK(dalloc(splits, (size_t)maxSplit));
+
+    uint32_t* orderCur = c->dOrder;
+    uint32_t* orderAlt = order2;
+    hipLaunchKernelGGL(k_build_reset, dim3(1), dim3(64), 0, st, c->dBuildNodes, cb, N);
+    hipLaunchKernelGGL(k_prim_boxes, dim3(cdiv(N, 256)), dim3(256), 0, st, c->dVerts, c->dIdx, N, pbox, orderCur,
+                       nodeOf, c->dBuildNodes, cb);
+    uint32_t levelStart = 0, levelCount = 1, nNodes = 1, depth = 1;
+    for(;;)
+    {
+        hipLaunchKernelGGL(k_level_flags, dim3(cdiv(levelCount, 256)), dim3(256), 0, st, c->dBuildNodes, levelStart,
+                           levelCount, rank);
+        rc = device_scan(c, rank, levelCount, tileSums, total);
+        if(rc) { cleanup(); return rc; }
+        uint32_t nsplit = 0;
+        BCHK(hipMemcpyAsync(&nsplit, total, 4, hipMemcpyDeviceToHost, st));
+        BCHK(hipStreamSynchronize(st));
+        if(nsplit == 0) break;
+        if(nsplit > maxSplit) { cleanup(); return fail(c, PRT_E_LIMIT, "prt_build_accel: split overflow"); }
+        hipLaunchKernelGGL(k_level_prepare, dim3(cdiv(levelCount, 256)), dim3(256), 0, st, c->dBuildNodes, levelStart,
+                           levelCount, rank, splits);
+        hipLaunchKernelGGL(k_split_of, dim3(cdiv(levelCount, 256)), dim3(256), 0, st, c->dBuildNodes, levelStart,
+                           levelCount, rank, splitOf);
+        hipLaunchKernelGGL(k_clear_bins, dim3(cdiv((size_t)nsplit * kBinWords, 256)), dim3(256), 0, st, bins, nsplit);
+        hipLaunchKernelGGL(k_bin, dim3(cdiv(N, 256)), dim3(256), 0, st, orderCur, nodeOf, c->dBuildNodes, cb, pbox,
+                           rank, levelStart, N, bins);
+        hipLaunchKernelGGL(k_split, dim3(cdiv(nsplit, 64)), dim3(64), 0, st, c->dBuildNodes, cb, bins, splits, nsplit,
+                           nNodes);
+        hipLaunchKernelGGL(k_flags, dim3(cdiv(N, 256)), dim3(256), 0, st, orderCur, nodeOf, splitOf, splits,
+                           c->dBuildNodes, pbox, levelStart, N, flags, scanBuf);
+        rc = device_scan(c, scanBuf, N, tileSums, total);
+        if(rc) { cleanup(); return rc; }
+        hipLaunchKernelGGL(k_scatter, dim3(cdiv(N, 256)), dim3(256), 0, st, orderCur, nodeOf, splitOf, splits,
+                           c->dBuildNodes, cb, pbox, flags, scanBuf, levelStart, N, orderAlt, nodeOf2);
+        BCHK(hipGetLastError());
+        std::swap(orderCur, orderAlt);
+        std::swap(nodeOf, nodeOf2);
+        levelStart = nNodes;
+        levelCount = 2 * nsplit;
+        nNodes += 2 * nsplit;
+        depth++;
+        if(depth > PRT_MAX_DEPTH)
+        {
+            cleanup();
+            return fail(c, PRT_E_LIMIT, "prt_build_accel: tree deeper than %d levels", PRT_MAX_DEPTH);
+        }
+    }
+    if(orderCur != c->dOrder)
+        BCHK(hipMemcpyAsync(c->dOrder, orderCur, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+
+    // traversal layout
+    hipLaunchKernelGGL(k_inner_flags, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, flags);
+    rc = device_scan(c, flags, nNodes, tileSums, total);
+    if(rc) { cleanup(); return rc; }
+    uint32_t nInner = 0;
+    BCHK(hipMemcpyAsync(&nInner, total, 4, hipMemcpyDeviceToHost, st));
+    BCHK(hipStreamSynchronize(st));
+    BCHK(dalloc(c->dNodes, (size_t)(nInner ? nInner : 1)));
+    BCHK(dalloc(c->dTris, (size_t)3 * N));
+    hipLaunchKernelGGL(k_emit_nodes, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, flags,
+                       c->dNodes);
+    hipLaunchKernelGGL(k_emit_tris, dim3(cdiv(N, 256)), dim3(256), 0, st, c->dVerts, c->dIdx, c->dOrder, N, c->dTris);
+    BCHK(hipGetLastError());
+    BuildNode rootNode;
+    BCHK(hipMemcpyAsync(&rootNode, c->dBuildNodes, sizeof rootNode, hipMemcpyDeviceToHost, st));
+    BCHK(hipStreamSynchronize(st));
+    cleanup();
+#undef BCHK
+    auto dec = [](uint32_t k) {
+        const uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+        float          f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    float sa = 0.0f;
+    for(int k = 0; k < 3; ++k)
+    {
+        const float a = fabsf(dec(rootNode.bmin[k])), b = fabsf(dec(rootNode.bmax[k]));
+        sa            = sa < a ? a : sa;
+        sa            = sa < b ? b : sa;
+    }
+    c->sceneAbs  = sa;
+    c->nNodes    = nNodes;
+    c->nInner    = nInner;
+    c->depth     = depth;
+    c->root      = nInner ? 0 : (int32_t) ~((0u << 3) | N);
+    c->haveAccel = true;
+    c->buildMs   = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PRT_OK;
+}
+
+int prt_set_scramble_seed(prt_context* c, uint32_t seed)
+{
+    if(!c) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(c->dScramble);
+    c->seed = seed;
+    return PRT_OK;
+}
+
+int prt_upload_scrambles(prt_context* c, const uint32_t* layers, uint32_t nlayers)
+{
+    if(!c) return PRT_E_INVALID;
+    if(!layers || nlayers != 32) return fail(c, PRT_E_INVALID, "prt_upload_scrambles: need 32 layers");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(c->dScramble);
+    HIPCHK(c, dalloc(c->dScramble, (size_t)32 * c->npix));
+    HIPCHK(c, hipMemcpy(c->dScramble, layers, (size_t)32 * c->npix * 4, hipMemcpyHostToDevice));
+    return PRT_OK;
+}
+
+int prt_set_uniforms(prt_context* c, const prt_uniforms* u)
+{
+    if(!c || !u) return PRT_E_INVALID;
+    if(u->numIndirectBounces < 0 || u->numIndirectBounces > (int)kMaxBounces)
+        return fail(c, PRT_E_LIMIT, "prt_set_uniforms: numIndirectBounces %d outside [0,%u]", u->numIndirectBounces,
+                    kMaxBounces);
+    if(u->numAArays < 0 || u->numAArays > 255) return fail(c, PRT_E_LIMIT, "prt_set_uniforms: numAArays %d", u->numAArays);
+    if(u->numAOrays < 0) return fail(c, PRT_E_INVALID, "prt_set_uniforms: numAOrays %d", u->numAOrays);
+    c->ubo = *u;
+    return PRT_OK;
+}
+
+int prt_set_flags(prt_context* c, uint32_t flags)
+{
+    if(!c) return PRT_E_INVALID;
+    c->flags = flags & (PRT_FLAG_LITERAL | PRT_FLAG_RUSSIAN_ROULETTE);
+    return PRT_OK;
+}
+
+static void make_views(prt_context* c, SceneView& sc, FrameView& f)
+{
+    sc.verts        = c->dVerts;
+    sc.idx          = c->dIdx;
+    sc.mats         = c->dMats;
+    sc.tex          = c->dTex;
+    sc.sobol        = c->dSobol;
+    sc.scrTable     = c->dScramble;
+    sc.nmats        = c->nmats;
+    sc.ntex         = c->ntex;
+    sc.seed         = c->seed;
+    sc.ntri         = c->ntri;
+    sc.bvh.nodes    = (const float4*)c->dNodes;
+    sc.bvh.tris     = c->dTris;
+    sc.bvh.root     = c->root;
+    sc.bvh.sceneAbs = c->sceneAbs;
+    f.w             = c->w;
+    f.h             = c->h;
+    f.npix          = c->npix;
+    f.accum         = c->accum;
+    f.rayO          = c->rayO;
+    f.rayD          = c->rayD;
+    f.hit           = c->hit;
+    f.thr           = c->thr;
+    f.shO           = c->shO;
+    f.shD           = c->shD;
+    f.eiVis         = c->eiVis;
+    f.eiOcc         = c->eiOcc;
+    f.aaOff         = c->aaOff;
+    f.hitIds        = c->hitIds;
+    f.dead          = c->dead;
+    f.stats         = c->stats;
+}
+
+// One vkCmdTraceRaysNV(W,H,1): a fixed launch sequence, no host synchronisation.
+static int render_one(prt_context* c, int mode)
+{
+    hipStream_t st = c->stream;
+    SceneView   sc;
+    FrameView   f;
+    make_views(c, sc, f);
+    // parameters for this iteration: the ring slot is reused only after kUboRing iterations
+    if(c->uboSlot == kUboRing)
+    {
+        HIPCHK(c, hipStreamSynchronize(st));
+        c->uboSlot = 0;
+    }
+    prt_uniforms* dU = c->dUbo + c->uboSlot;
+    prt_uniforms* hU = c->hUbo + c->uboSlot;
+    c->uboSlot++;
+    *hU = c->ubo;
+    HIPCHK(c, hipMemcpyAsync(dU, hU, sizeof(prt_uniforms), hipMemcpyHostToDevice, st));
+    const uint32_t gridPix   = cdiv(c->npix, 256);
+    const uint32_t gridTrace = (uint32_t)c->numCU * 6u;
+    const uint32_t gridShade = (uint32_t)c->numCU * 8u;
+    if(mode == PRT_MODE_AO)
+    {
+        HIPCHK(c, hipMemsetAsync(c->counters, 0, kCounterWords * 4, st));
+        hipLaunchKernelGGL(k_ao_generate, dim3(gridPix), dim3(256), 0, st, f, (const prt_uniforms*)dU, c->flags);
+        hipLaunchKernelGGL(k_extend, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, c->counters + 0, 1u);
+        hipLaunchKernelGGL(k_ao_shade, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, (const prt_uniforms*)dU,
+                           c->flags, c->counters + 1);
+        HIPCHK(c, hipGetLastError());
+        c->iterations++;
+        return PRT_OK;
+    }
+    const int B = c->ubo.numIndirectBounces;
+    for(int aa = 0; aa < c->ubo.numAArays; ++aa)
+    {
+        // counters: [0..31] path-queue lengths per bounce, [32..63] shadow-queue lengths,
+        //           [64..127] work-fetch cursors of the extend launches, [128..191] of the shadow launches
+        HIPCHK(c, hipMemsetAsync(c->counters, 0, kCounterWords * 4, st));
+        const uint32_t fl = c->flags | ((uint32_t)aa << 8);
+        hipLaunchKernelGGL(k_generate, dim3(gridPix), dim3(256), 0, st, sc, f, (const prt_uniforms*)dU, c->flags,
+                           (uint32_t)aa);
+        for(int b = 0; b <= B; ++b)
+        {
+            const uint32_t* qIn  = b == 0 ? nullptr : c->q[b & 1];
+            const uint32_t* nIn  = b == 0 ? nullptr : c->counters + b;
+            uint32_t*       qOut = c->q[(b + 1) & 1];
+            hipLaunchKernelGGL(k_extend, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, qIn, nIn,
+                               c->counters + 64 + b, b == 0 ? 1u : 0u);
+            hipLaunchKernelGGL(k_shade, dim3(gridShade), dim3(256), 0, st, sc, f, (const prt_uniforms*)dU, fl,
+                               (uint32_t)b, qIn, nIn, qOut, c->counters + b + 1, c->qShadow, c->counters + 32 + b);
+            hipLaunchKernelGGL(k_shadow, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+                               (const uint32_t*)c->qShadow, (const uint32_t*)(c->counters + 32 + b),
+                               c->counters + 128 + b);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    c->iterations++;
+    return PRT_OK;
+}
+
+int prt_render_iteration(prt_context* c, int mode)
+{
+    if(!c) return PRT_E_INVALID;
+    if(mode != PRT_MODE_PATH && mode != PRT_MODE_AO) return fail(c, PRT_E_INVALID, "prt_render_iteration: mode %d", mode);
+    if(!c->haveAccel) return fail(c, PRT_E_NOSCENE, "prt_render_iteration: no acceleration structure");
+    HIPCHK(c, hipSetDevice(c->device));
+    return render_one(c, mode);
+}
+
+int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t stride)
+{
+    if(!c) return PRT_E_INVALID;
+    if(stride == 0) return fail(c, PRT_E_INVALID, "prt_render: stride 0");
+    for(uint32_t k = 0; k < n; ++k)
+    {
+        c->ubo.iteration = first + k * stride;
+        const int rc     = prt_render_iteration(c, mode);
+        if(rc) return rc;
+    }
+    return PRT_OK;
+}
+
+int prt_sync(prt_context* c)
+{
+    if(!c) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PRT_OK;
+}
+
+int prt_clear_accum(prt_context* c)
+{
+    if(!c) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->accum, 0, (size_t)c->npix * sizeof(float4), c->stream));
+    return PRT_OK;
+}
+
+int prt_read_accum(prt_context* c, float* out)
+{
+    if(!c || !out) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->accum, (size_t)c->npix * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PRT_OK;
+}
+
+int prt_device_accum_ptr(prt_context* c, void** p)
+{
+    if(!c || !p) return PRT_E_INVALID;
+    *p = c->accum;
+    return PRT_OK;
+}
+
+int prt_bind_accum(prt_context* c, void* p)
+{
+    if(!c) return PRT_E_INVALID;
+    if(((uintptr_t)p & 15u) != 0) return fail(c, PRT_E_INVALID, "prt_bind_accum: pointer not 16-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->accum = p ? (float4*)p : c->accumOwn;
+    return PRT_OK;
+}
+
+int prt_postprocess(prt_context* c, uint8_t* out)
+{
+    if(!c || !out) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t* d = nullptr;
+    HIPCHK(c, dalloc(d, (size_t)c->npix));
+    hipLaunchKernelGGL(k_postprocess, dim3(cdiv(c->npix, 256)), dim3(256), 0, c->stream, (const float4*)c->accum,
+                       c->npix, d);
+    hipError_t e = hipMemcpyAsync(out, d, (size_t)c->npix * 4, hipMemcpyDeviceToHost, c->stream);
+    if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dfree(d);
+    HIPCHK(c, e);
+    return PRT_OK;
+}
+
+int prt_read_hit_ids(prt_context* c, uint32_t* out)
+{
+    if(!c || !out) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->hitIds, (size_t)c->npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PRT_OK;
+}
+
+int prt_get_stats(prt_context* c, prt_stats* s)
+{
+    if(!c || !s) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long rays = 0;
+    HIPCHK(c, hipMemcpyAsync(&rays, c->stats, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    s->rays            = rays;
+    s->iterations      = c->iterations;
+    s->bvh_nodes       = c->nNodes;
+    s->bvh_inner_nodes = c->nInner;
+    s->bvh_depth       = c->depth;
+    s->bvh_build_ms    = c->buildMs;
+    return PRT_OK;
+}
+
+int prt_reset_stats(prt_context* c)
+{
+    if(!c) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->stats, 0, 4 * sizeof(unsigned long long), c->stream));
+    c->iterations = 0;
+    return PRT_OK;
+}
+
+int prt_trace_device(prt_context* c, const void* rays, size_t n, int any, void* hits, float* ms)
+{
+    if(!c || !rays || !hits) return PRT_E_INVALID;
+    if(!c->haveAccel) return fail(c, PRT_E_NOSCENE, "prt_trace: no acceleration structure");
+    if(n >= (1ull << 31)) return fail(c, PRT_E_LIMIT, "prt_trace: too many rays");
+    HIPCHK(c, hipSetDevice(c->device));
+    if(n == 0) { if(ms) *ms = 0.0f; return PRT_OK; }
+    SceneView sc;
+    FrameView f;
+    make_views(c, sc, f);
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    if(any)
+        hipLaunchKernelGGL(k_trace_batch<true>, dim3(cdiv(n, PRT_TRACE_BLOCK)), dim3(PRT_TRACE_BLOCK), 0, c->stream,
+                           sc.bvh, (const float4*)rays, (uint32_t)n, (float4*)hits);
+    else
+        hipLaunchKernelGGL(k_trace_batch<false>, dim3(cdiv(n, PRT_TRACE_BLOCK)), dim3(PRT_TRACE_BLOCK), 0, c->stream,
+                           sc.bvh, (const float4*)rays, (uint32_t)n, (float4*)hits);
+    hipError_t e = hipGetLastError();
+    if(e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if(e == hipSuccess) e = hipEventSynchronize(e1);
+    float t = 0.0f;
+    if(e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(c, e);
+    if(ms) *ms = t;
+    return PRT_OK;
+}
+
+int prt_trace(prt_context* c, const prt_ray* rays, size_t n, int any, prt_hit* out)
+{
+    if(!c || (n && (!rays || !out))) return PRT_E_INVALID;
+    if(n == 0) return PRT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    float4 *dr = nullptr, *dh = nullptr;
+    HIPCHK(c, dalloc(dr, 2 * n));
+    hipError_t e = dalloc(dh, n);
+    if(e == hipSuccess) e = hipMemcpy(dr, rays, n * sizeof(prt_ray), hipMemcpyHostToDevice);
+    int rc = PRT_OK;
+    if(e == hipSuccess) rc = prt_trace_device(c, dr, n, any, dh, nullptr);
+    if(e == hipSuccess && rc == PRT_OK) e = hipMemcpy(out, dh, n * sizeof(prt_hit), hipMemcpyDeviceToHost);
+    dfree(dr);
+    dfree(dh);
+    if(rc) return rc;
+    HIPCHK(c, e);
+    return PRT_OK;
+}
+
+int prt_read_bvh(prt_context* c, prt_bvh_node* nodes, uint32_t* order)
+{
+    if(!c) return PRT_E_INVALID;
+    if(!c->haveAccel) return fail(c, PRT_E_NOSCENE, "prt_read_bvh: no acceleration structure");
+    HIPCHK(c, hipSetDevice(c->device));
+    if(nodes)
+    {
+        float4* d = nullptr;
+        HIPCHK(c, dalloc(d, (size_t)2 * c->nNodes));
+        hipLaunchKernelGGL(k_decode_nodes, dim3(cdiv(c->nNodes, 256)), dim3(256), 0, c->stream, c->dBuildNodes,
+                           c->nNodes, d);
+        hipError_t e = hipMemcpyAsync(nodes, d, (size_t)c->nNodes * 32, hipMemcpyDeviceToHost, c->stream);
+        if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        dfree(d);
+        HIPCHK(c, e);
+    }
+    if(order) HIPCHK(c, hipMemcpy(order, c->dOrder, (size_t)c->ntri * 4, hipMemcpyDeviceToHost));
+    return PRT_OK;
+}
+
+int prt_read_sobol(prt_context* c, uint32_t* out)
+{
+    if(!c || !out) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(out, c->dSobol, 64 * 32 * 4, hipMemcpyDeviceToHost));
+    return PRT_OK;
+}
+
+}  // extern "C"

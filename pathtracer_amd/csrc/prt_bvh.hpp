@@ -1,0 +1,550 @@
+// prt_bvh.hpp — binned-SAH BVH build on the GPU: replaces the BLAS/TLAS construction that the
+// reference hands to vkCmdBuildAccelerationStructureNV (src/vkRTX_setup.cpp:84-132,138-186,391-415;
+// external/NVIDIA_RTX/vkRT_BLAS.cpp:271). One instance, identity transform, opaque, two-sided:
+// a single-level BVH over the triangles of model 0.
+//
+// Algorithm: breadth-first, one pass of kernels per tree level, 16 bins per axis, leaves <= 4
+// triangles. Everything that decides the tree is order-independent: bin counts are integer
+// atomics, bin / node / centroid bounds are integer atomicMin/Max on order-preserving float keys,
+// SAH costs are evaluated per node in a fixed order, child slots and the stable partition come
+// from prefix sums. The same input therefore always yields the same tree, bit for bit.
+#pragma once
+#include "prt_trace.hpp"
+
+namespace prt {
+
+constexpr int      kBins    = 16;
+constexpr uint32_t kLeafMax = 4;
+constexpr uint32_t kBinWords = 3 * kBins * 7;  // per splitting node: cnt[3][16], min[3][16][3], max[3][16][3]
+
+struct BuildNode  // bounds as ordered keys while building
+{
+    uint32_t bmin[3];
+    uint32_t first;
+    uint32_t bmax[3];
+    uint32_t count;
+};
+struct SplitRec
+{
+    int32_t  axis;  // -1: no usable plane, cut the range in the middle
+    int32_t  split;
+    float    scale;
+    float    cmin;
+    uint32_t nL;
+    uint32_t node;
+    uint32_t child;
+    uint32_t pad;
+};
+
+PRT_DEV uint32_t fkey(float f)
+{
+    const uint32_t u = (uint32_t)__float_as_int(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+PRT_DEV float fdec(uint32_t k)
+{
+    const uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+    return __int_as_float((int)u);
+}
+constexpr uint32_t kKeyPosInf = 0xFF800000u;  // fkey(+inf)
+constexpr uint32_t kKeyNegInf = 0x007FFFFFu;  // fkey(-inf)
+
+PRT_DEV int bin_of(float c, float cmin, float scale)
+{
+    int b = (int)((c - cmin) * scale);
+    return b > kBins - 1 ? kBins - 1 : b;
+}
+
+// ---- exclusive scan (3 kernels) ---------------------------------------------------------------
+#define PRT_SCAN_BLOCK 256
+#define PRT_SCAN_ITEMS 4
+#define PRT_SCAN_TILE (PRT_SCAN_BLOCK * PRT_SCAN_ITEMS)
+
+PRT_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds /*[PRT_SCAN_BLOCK/64]*/, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t  inc  = v;
+#pragma unroll
+    for(int o = 1; o < 64; o <<= 1)
+    {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if(lane >= o) inc += t;
+    }
+    if(lane == 63) lds[wid] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for(int w = 0; w < PRT_SCAN_BLOCK / 64; ++w)
+    {
+        const uint32_t s = lds[w];
+        if(w < wid) off += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return off + inc - v;
+}
+
+__global__ void __launch_bounds__(PRT_SCAN_BLOCK) k_scan_tiles(uint32_t* __restrict__ data, uint32_t n,
+                                                              uint32_t* __restrict__ tileSums)
+{
+    __shared__ uint32_t lds[PRT_SCAN_BLOCK / 64];
+    const uint32_t      base = blockIdx.x * PRT_SCAN_TILE + threadIdx.x * PRT_SCAN_ITEMS;
+    uint32_t            v[PRT_SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for(int k = 0; k < PRT_SCAN_ITEMS; ++k)
+    {
+        v[k] = (base + k < n) ? data[base + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(sum, lds, total);
+#pragma unroll
+    for(int k = 0; k < PRT_SCAN_ITEMS; ++k)
+    {
+        if(base + k < n) data[base + k] = run;
+        run += v[k];
+    }
+    if(threadIdx.x == 0) tileSums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(PRT_SCAN_BLOCK) k_scan_sums(uint32_t* __restrict__ tileSums, uint32_t ntiles,
+                                                             uint32_t* __restrict__ totalOut)
+{
+    __shared__ uint32_t lds[PRT_SCAN_BLOCK / 64];
+    uint32_t            carry = 0;
+    for(uint32_t base = 0; base < ntiles; base += PRT_SCAN_BLOCK)
+    {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < ntiles ? tileSums[i] : 0u;
+        uint32_t       total;
+        const uint32_t e = block_exclusive_scan(v, lds, total);
+        if(i < ntiles) tileSums[i] = carry + e;
+        carry += total;
+    }
+    if(threadIdx.x == 0) *totalOut = carry;
+}
+__global__ void __launch_bounds__(PRT_SCAN_BLOCK) k_scan_add(uint32_t* __restrict__ data, uint32_t n,
+                                                            const uint32_t* __restrict__ tileSums)
+{
+    const uint32_t base = blockIdx.x * PRT_SCAN_TILE + threadIdx.x * PRT_SCAN_ITEMS;
+    const uint32_t off  = tileSums[blockIdx.x];
+#pragma unroll
+    for(int k = 0; k < PRT_SCAN_ITEMS; ++k)
+        if(base + k < n) data[base + k] += off;
+}
+
+// ---- build kernels ------------------------------------------------------------------------------
+__global__ void k_build_reset(BuildNode* nodes, uint32_t* cb, uint32_t ntri)
+{
+    if(threadIdx.x == 0 && blockIdx.x == 0)
+    {
+        for(int k = 0; k < 3; ++k)
+        {
+            nodes[0].bmin[k] = kKeyPosInf;
+            nodes[0].bmax[k] = kKeyNegInf;
+            cb[k]            = kKeyPosInf;
+            cb[3 + k]        = kKeyNegInf;
+        }
+        nodes[0].first = 0;
+        nodes[0].count = ntri;
+    }
+}
+
+// per-triangle box (exact min/max of the three vertices), identity order, root bounds
+__global__ void __launch_bounds__(256) k_prim_boxes(const prt_vertex* __restrict__ verts,
+                                                    const uint32_t* __restrict__ idx, uint32_t ntri,
+                                                    float4* __restrict__ pbox, uint32_t* __restrict__ order,
+                                                    uint32_t* __restrict__ nodeOf, BuildNode* nodes, uint32_t* cb)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       kmn[3] = {kKeyPosInf, kKeyPosInf, kKeyPosInf}, kmx[3] = {kKeyNegInf, kKeyNegInf, kKeyNegInf};
+    uint32_t       cmn[3] = {kKeyPosInf, kKeyPosInf, kKeyPosInf}, cmx[3] = {kKeyNegInf, kKeyNegInf, kKeyNegInf};
+    if(i < ntri)
+    {
+        for(int k = 0; k < 3; ++k)
+        {
+            const float* p = verts[idx[3 * i + k]].p;
+            for(int a = 0; a < 3; ++a)
+            {
+                const uint32_t key = fkey(p[a]);
+                kmn[a]             = min(kmn[a], key);
+                kmx[a]             = max(kmx[a], key);
+            }
+        }
+        const float mn[3] = {fdec(kmn[0]), fdec(kmn[1]), fdec(kmn[2])};
+        const float mx[3] = {fdec(kmx[0]), fdec(kmx[1]), fdec(kmx[2])};
+        pbox[2 * i]       = make_float4(mn[0], mn[1], mn[2], 0.0f);
+        pbox[2 * i + 1]   = make_float4(mx[0], mx[1], mx[2], 0.0f);
+        order[i]          = i;
+        nodeOf[i]         = 0;
+        for(int a = 0; a < 3; ++a)
+        {
+            const uint32_t ck = fkey((mn[a] + mx[a]) * 0.5f);
+            cmn[a]            = ck;
+            cmx[a]            = ck;
+        }
+    }
+    // wave-level reduction, then one atomic per wave and bound
+    for(int a = 0; a < 3; ++a)
+    {
+        for(int o = 32; o > 0; o >>= 1)
+        {
+            kmn[a] = min(kmn[a], (uint32_t)__shfl_xor((int)kmn[a], o, 64));
+            kmx[a] = max(kmx[a], (uint32_t)__shfl_xor((int)kmx[a], o, 64));
+            cmn[a] = min(cmn[a], (uint32_t)__shfl_xor((int)cmn[a], o, 64));
+            cmx[a] = max(cmx[a], (uint32_t)__shfl_xor((int)cmx[a], o, 64));
+        }
+        if((threadIdx.x & 63) == 0)
+        {
+            atomicMin(&nodes[0].bmin[a], kmn[a]);
+            atomicMax(&nodes[0].bmax[a], kmx[a]);
+            atomicMin(&cb[a], cmn[a]);
+            atomicMax(&cb[3 + a], cmx[a]);
+        }
+    }
+}
+
+// flags[j] = 1 when node levelStart+j must be split
+__global__ void __launch_bounds__(256) k_level_flags(const BuildNode* __restrict__ nodes, uint32_t levelStart,
+                                                     uint32_t levelCount, uint32_t* __restrict__ flags)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j < levelCount) flags[j] = nodes[levelStart + j].count > kLeafMax ? 1u : 0u;
+}
+
+// after the scan: rank[j] valid for splitting nodes; record node id per split, clear the bins
+__global__ void __launch_bounds__(256) k_level_prepare(const BuildNode* __restrict__ nodes, uint32_t levelStart,
+                                                       uint32_t levelCount, const uint32_t* __restrict__ rank,
+                                                       SplitRec* __restrict__ splits)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j < levelCount && nodes[levelStart + j].count > kLeafMax) splits[rank[j]].node = levelStart + j;
+}
+__global__ void __launch_bounds__(256) k_clear_bins(uint32_t* __restrict__ bins, uint32_t nsplit)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= (size_t)nsplit * kBinWords) return;
+    const uint32_t w = (uint32_t)(i % kBinWords);
+    bins[i]          = w < 3 * kBins ? 0u : (w < 3 * kBins * 4 ? kKeyPosInf : kKeyNegInf);
+}
+
+// every triangle of a splitting node drops its box into one bin per axis
+__global__ void __launch_bounds__(256) k_bin(const uint32_t* __restrict__ order, const uint32_t* __restrict__ nodeOf,
+                                             const BuildNode* __restrict__ nodes, const uint32_t* __restrict__ cb,
+                                             const float4* __restrict__ pbox, const uint32_t* __restrict__ rank,
+                                             uint32_t levelStart, uint32_t ntri, uint32_t* __restrict__ bins)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= ntri) return;
+    const uint32_t ni = nodeOf[i];
+    if(nodes[ni].count <= kLeafMax) return;
+    const uint32_t p  = order[i];
+    const float4   mn = pbox[2 * p], mx = pbox[2 * p + 1];
+    const float    c[3]  = {(mn.x + mx.x) * 0.5f, (mn.y + mx.y) * 0.5f, (mn.z + mx.z) * 0.5f};
+    const uint32_t km[3] = {fkey(mn.x), fkey(mn.y), fkey(mn.z)};
+    const uint32_t kx[3] = {fkey(mx.x), fkey(mx.y), fkey(mx.z)};
+    uint32_t*      B     = bins + (size_t)rank[ni - levelStart] * kBinWords;
+    for(int a = 0; a < 3; ++a)
+    {
+        const float cmin = fdec(cb[6 * ni + a]), cmax = fdec(cb[6 * ni + 3 + a]);
+        const float ext = cmax - cmin;
+        if(!(ext > 0.0f)) continue;
+        const float scale = (float)kBins / ext;
+        const int   b     = bin_of(c[a], cmin, scale);
+        atomicAdd(&B[a * kBins + b], 1u);
+        uint32_t* bmn = B + 3 * kBins + (a * kBins + b) * 3;
+        uint32_t* bmx = B + 3 * kBins * 4 + (a * kBins + b) * 3;
+        for(int k = 0; k < 3; ++k)
+        {
+            atomicMin(&bmn[k], km[k]);
+            atomicMax(&bmx[k], kx[k]);
+        }
+    }
+}
+
+struct KBox
+{
+    uint32_t mn[3], mx[3];
+};
+PRT_DEV void kbox_empty(KBox& b)
+{
+    for(int k = 0; k < 3; ++k) { b.mn[k] = kKeyPosInf; b.mx[k] = kKeyNegInf; }
+}
+PRT_DEV float kbox_area(const KBox& b)
+{
+    const float dx = fdec(b.mx[0]) - fdec(b.mn[0]), dy = fdec(b.mx[1]) - fdec(b.mn[1]),
+                dz = fdec(b.mx[2]) - fdec(b.mn[2]);
+    return ((dx * dy) + (dy * dz)) + (dz * dx);
+}
+
+// one thread per splitting node: sweep 3 x 15 planes, keep the cheapest (first wins ties), emit children
+__global__ void __launch_bounds__(64) k_split(BuildNode* __restrict__ nodes, uint32_t* __restrict__ cb,
+                                              const uint32_t* __restrict__ bins, SplitRec* __restrict__ splits,
+                                              uint32_t nsplit, uint32_t childBase)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if(s >= nsplit) return;
+    const uint32_t  ni    = splits[s].node;
+    const uint32_t  start = nodes[ni].first, count = nodes[ni].count;
+    const uint32_t* B     = bins + (size_t)s * kBinWords;
+    float           bestCost = __builtin_inff();
+    int             bestAxis = -1, bestSplit = 0;
+    float           bestScale = 0.0f, bestCmin = 0.0f;
+    uint32_t        bestNL = 0;
+    KBox            bestL, bestR;
+    kbox_empty(bestL);
+    kbox_empty(bestR);
+    for(int a = 0; a < 3; ++a)
+    {
+        const float cmin = fdec(cb[6 * ni + a]), cmax = fdec(cb[6 * ni + 3 + a]);
+        const float ext = cmax - cmin;
+        if(!(ext > 0.0f)) continue;
+        const float     scale = (float)kBins / ext;
+        const uint32_t* cnt   = B + a * kBins;
+        const uint32_t* bmn   = B + 3 * kBins + a * kBins * 3;
+        const uint32_t* bmx   = B + 3 * kBins * 4 + a * kBins * 3;
+        // suffix areas / counts
+        float    areaR[kBins];
+        uint32_t nRs[kBins];
+        KBox     acc;
+        kbox_empty(acc);
+        uint32_t nacc = 0;
+        for(int b = kBins - 1; b >= 1; --b)
+        {
+            for(int k = 0; k < 3; ++k)
+            {
+                acc.mn[k] = min(acc.mn[k], bmn[b * 3 + k]);
+                acc.mx[k] = max(acc.mx[k], bmx[b * 3 + k]);
+            }
+            nacc += cnt[b];
+            nRs[b]   = nacc;
+            areaR[b] = nacc ? kbox_area(acc) : 0.0f;
+        }
+        KBox L;
+        kbox_empty(L);
+        uint32_t nL = 0;
+        for(int sp = 1; sp < kBins; ++sp)
+        {
+            for(int k = 0; k < 3; ++k)
+            {
+                L.mn[k] = min(L.mn[k], bmn[(sp - 1) * 3 + k]);
+                L.mx[k] = max(L.mx[k], bmx[(sp - 1) * 3 + k]);
+            }
+            nL += cnt[sp - 1];
+            const uint32_t nR = nRs[sp];
+            if(nL == 0 || nR == 0) continue;
+            const float cost = (kbox_area(L) * (float)nL) + (areaR[sp] * (float)nR);
+            if(cost < bestCost)
+            {
+                bestCost  = cost;
+                bestAxis  = a;
+                bestSplit = sp;
+                bestScale = scale;
+                bestCmin  = cmin;
+                bestNL    = nL;
+                bestL     = L;
+            }
+        }
+    }
+    if(bestAxis >= 0)
+    {
+        // right box of the winning plane
+        const uint32_t* bmn = B + 3 * kBins + bestAxis * kBins * 3;
+        const uint32_t* bmx = B + 3 * kBins * 4 + bestAxis * kBins * 3;
+        for(int b = bestSplit; b < kBins; ++b)
+            for(int k = 0; k < 3; ++k)
+            {
+                bestR.mn[k] = min(bestR.mn[k], bmn[b * 3 + k]);
+                bestR.mx[k] = max(bestR.mx[k], bmx[b * 3 + k]);
+            }
+    }
+    else
+    {
+        bestNL = count / 2;  // boxes are accumulated by k_scatter
+    }
+    const uint32_t child = childBase + 2 * s;
+    SplitRec       r;
+    r.axis  = bestAxis;
+    r.split = bestSplit;
+    r.scale = bestScale;
+    r.cmin  = bestCmin;
+    r.nL    = bestNL;
+    r.node  = ni;
+    r.child = child;
+    r.pad   = 0;
+    splits[s] = r;
+    BuildNode l, rr;
+    for(int k = 0; k < 3; ++k)
+    {
+        l.bmin[k]  = bestL.mn[k];
+        l.bmax[k]  = bestL.mx[k];
+        rr.bmin[k] = bestR.mn[k];
+        rr.bmax[k] = bestR.mx[k];
+    }
+    l.first  = start;
+    l.count  = bestNL;
+    rr.first = start + bestNL;
+    rr.count = count - bestNL;
+    nodes[child]     = l;
+    nodes[child + 1] = rr;
+    nodes[ni].first  = child;
+    nodes[ni].count  = 0;
+    for(int k = 0; k < 3; ++k)
+    {
+        cb[6 * child + k]           = kKeyPosInf;
+        cb[6 * child + 3 + k]       = kKeyNegInf;
+        cb[6 * (child + 1) + k]     = kKeyPosInf;
+        cb[6 * (child + 1) + 3 + k] = kKeyNegInf;
+    }
+}
+
+// NOTE: k_flags / k_scatter run after k_split rewrote nodes[ni] (count = 0, first = child), so they
+// identify splitting nodes through `splitOf` (rank per level node, ~0u for leaves) captured before.
+__global__ void __launch_bounds__(256) k_split_of(const BuildNode* __restrict__ nodes, uint32_t levelStart,
+                                                  uint32_t levelCount, const uint32_t* __restrict__ rank,
+                                                  uint32_t* __restrict__ splitOf)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j < levelCount) splitOf[j] = nodes[levelStart + j].count > kLeafMax ? rank[j] : 0xffffffffu;
+}
+
+__global__ void __launch_bounds__(256) k_flags(const uint32_t* __restrict__ order, const uint32_t* __restrict__ nodeOf,
+                                               const uint32_t* __restrict__ splitOf, const SplitRec* __restrict__ splits,
+                                               const BuildNode* __restrict__ nodes, const float4* __restrict__ pbox,
+                                               uint32_t levelStart, uint32_t ntri, uint32_t* __restrict__ flags,
+                                               uint32_t* __restrict__ scanBuf)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= ntri) return;
+    const uint32_t ni = nodeOf[i];
+    uint32_t       f  = 0;
+    if(ni >= levelStart)
+    {
+        const uint32_t s = splitOf[ni - levelStart];
+        if(s != 0xffffffffu)
+        {
+            const SplitRec r = splits[s];
+            if(r.axis >= 0)
+            {
+                const uint32_t p  = order[i];
+                const float4   mn = pbox[2 * p], mx = pbox[2 * p + 1];
+                const float    c  = r.axis == 0 ? (mn.x + mx.x) * 0.5f
+                                                : (r.axis == 1 ? (mn.y + mx.y) * 0.5f : (mn.z + mx.z) * 0.5f);
+                f = bin_of(c, r.cmin, r.scale) < r.split ? 1u : 0u;
+            }
+            else
+            {
+                // median cut: the first nL positions of the range (range start = left child's first)
+                f = (i - nodes[r.child].first) < r.nL ? 1u : 0u;
+            }
+        }
+    }
+    flags[i]   = f;
+    scanBuf[i] = f;
+}
+__global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ order, const uint32_t* __restrict__ nodeOf,
+                                                 const uint32_t* __restrict__ splitOf,
+                                                 const SplitRec* __restrict__ splits, BuildNode* nodes,
+                                                 uint32_t* cb, const float4* __restrict__ pbox,
+                                                 const uint32_t* __restrict__ flagsIn,
+                                                 const uint32_t* __restrict__ scanL, uint32_t levelStart,
+                                                 uint32_t ntri, uint32_t* __restrict__ orderOut,
+                                                 uint32_t* __restrict__ nodeOfOut)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= ntri) return;
+    const uint32_t ni = nodeOf[i];
+    const uint32_t p  = order[i];
+    uint32_t       s  = 0xffffffffu;
+    if(ni >= levelStart) s = splitOf[ni - levelStart];
+    if(s == 0xffffffffu)
+    {
+        orderOut[i]  = p;
+        nodeOfOut[i] = ni;
+        return;
+    }
+    const SplitRec r     = splits[s];
+    const uint32_t start = nodes[r.child].first;
+    const uint32_t lBefore = scanL[i] - scanL[start];
+    const bool     left    = flagsIn[i] != 0u;
+    const uint32_t pos     = left ? start + lBefore : start + r.nL + ((i - start) - lBefore);
+    const uint32_t child   = left ? r.child : r.child + 1;
+    orderOut[pos]          = p;
+    nodeOfOut[pos]         = child;
+    const float4 mn = pbox[2 * p], mx = pbox[2 * p + 1];
+    const float  c[3] = {(mn.x + mx.x) * 0.5f, (mn.y + mx.y) * 0.5f, (mn.z + mx.z) * 0.5f};
+    for(int a = 0; a < 3; ++a)
+    {
+        const uint32_t ck = fkey(c[a]);
+        atomicMin(&cb[6 * child + a], ck);
+        atomicMax(&cb[6 * child + 3 + a], ck);
+    }
+    if(r.axis < 0)
+    {
+        const float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
+        for(int a = 0; a < 3; ++a)
+        {
+            atomicMin(&nodes[child].bmin[a], fkey(lo[a]));
+            atomicMax(&nodes[child].bmax[a], fkey(hi[a]));
+        }
+    }
+}
+
+// ---- emit the traversal layout -----------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_inner_flags(const BuildNode* __restrict__ nodes, uint32_t nnodes,
+                                                     uint32_t* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < nnodes) flags[i] = nodes[i].count == 0 ? 1u : 0u;
+}
+PRT_DEV int32_t child_ref(const BuildNode& c, uint32_t ci, const uint32_t* innerIdx)
+{
+    return c.count == 0 ? (int32_t)innerIdx[ci] : (int32_t)~((c.first << 3) | c.count);
+}
+__global__ void __launch_bounds__(256) k_emit_nodes(const BuildNode* __restrict__ nodes, uint32_t nnodes,
+                                                    const uint32_t* __restrict__ innerIdx, Node64* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= nnodes || nodes[i].count != 0) return;
+    const uint32_t  li = nodes[i].first, ri = li + 1;
+    const BuildNode l = nodes[li], r = nodes[ri];
+    Node64          n;
+    for(int k = 0; k < 3; ++k)
+    {
+        n.lmin[k] = fdec(l.bmin[k]);
+        n.lmax[k] = fdec(l.bmax[k]);
+        n.rmin[k] = fdec(r.bmin[k]);
+        n.rmax[k] = fdec(r.bmax[k]);
+    }
+    n.left  = child_ref(l, li, innerIdx);
+    n.right = child_ref(r, ri, innerIdx);
+    n.pad0 = n.pad1 = 0;
+    out[innerIdx[i]] = n;
+}
+__global__ void __launch_bounds__(256) k_emit_tris(const prt_vertex* __restrict__ verts,
+                                                   const uint32_t* __restrict__ idx,
+                                                   const uint32_t* __restrict__ order, uint32_t ntri,
+                                                   float4* __restrict__ tris)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= ntri) return;
+    const uint32_t p  = order[i];
+    const float*   a  = verts[idx[3 * p]].p;
+    const float*   b  = verts[idx[3 * p + 1]].p;
+    const float*   c  = verts[idx[3 * p + 2]].p;
+    tris[3 * i]       = make_float4(a[0], a[1], a[2], __int_as_float((int)p));
+    tris[3 * i + 1]   = make_float4(b[0], b[1], b[2], 0.0f);
+    tris[3 * i + 2]   = make_float4(c[0], c[1], c[2], 0.0f);
+}
+// float view of the build nodes for prt_read_bvh()
+__global__ void __launch_bounds__(256) k_decode_nodes(const BuildNode* __restrict__ nodes, uint32_t nnodes,
+                                                      float4* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= nnodes) return;
+    const BuildNode n = nodes[i];
+    out[2 * i]     = make_float4(fdec(n.bmin[0]), fdec(n.bmin[1]), fdec(n.bmin[2]), __int_as_float((int)n.first));
+    out[2 * i + 1] = make_float4(fdec(n.bmax[0]), fdec(n.bmax[1]), fdec(n.bmax[2]), __int_as_float((int)n.count));
+}
+
+}  // namespace prt

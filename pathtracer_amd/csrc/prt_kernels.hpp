@@ -1,0 +1,605 @@
+// prt_kernels.hpp — the pathRT / AO integrators as wavefront kernels for gfx950.
+//
+// The reference runs one megakernel ray-gen invocation per pixel (shaders/pathRT.rgen:621-974,
+// shaders/AO.rgen:183-273) and leaves divergence to the RT hardware's scheduler. Here one
+// iteration is a fixed sequence of launches with no host round trip:
+//
+//   generate -> [ extend -> shade -> shadow+connect ] x (numIndirectBounces + 1)
+//
+//   generate  : Sobol pixel jitter, primary ray                         (pathRT.rgen:627-690)
+//   extend    : closest-hit traversal of the queued rays                (traceNV :692, :963)
+//   shade     : vertex/material fetch, textures, bump, light sample, GGX VNDF sample, termination;
+//               emits the shadow ray + both possible radiance terms and the next ray;
+//               surviving paths are compacted into the next queue with wave ballots  (:699-961)
+//   shadow    : any-hit traversal, then E += (visible ? Ei_vis : Ei_occ, color.w)   (:818-847,:939-942)
+//
+// All per-path state is pixel-indexed SoA (float4 records -> 16-byte coalesced accesses); queues
+// hold pixel ids. Queue lengths live in device memory, kernels are persistent (wave-granular work
+// fetch), so the launch sequence is identical every iteration.
+#pragma once
+#include "prt_trace.hpp"
+
+namespace prt {
+
+#define PRT_FLAG_LITERAL 1u
+#define PRT_FLAG_RUSSIAN_ROULETTE 2u
+
+struct SceneView
+{
+    const prt_vertex*   verts;
+    const uint32_t*     idx;
+    const prt_material* mats;
+    const TexDesc*      tex;
+    const uint32_t*     sobol;     // [64][32]
+    const uint32_t*     scrTable;  // optional [32][npix]
+    uint32_t            nmats, ntex, seed, ntri;
+    BvhView             bvh;
+};
+
+struct FrameView
+{
+    uint32_t  w, h, npix;
+    float4*   accum;
+    float4*   rayO;   // Ro.xyz, tmin
+    float4*   rayD;   // Rd.xyz, tmax
+    float4*   hit;    // prim bits, u, v, t
+    float4*   thr;    // throughput.xyz, p
+    float4*   shO;    // hitPoint.xyz, color.w
+    float4*   shD;    // vLight.xyz, -
+    float4*   eiVis;  // radiance term if the light sample is visible
+    float4*   eiOcc;  // radiance term if it is occluded
+    float2*   aaOff;  // rayOffset (only read when numAArays != 1)
+    uint32_t* hitIds; // primary-ray primitive id per pixel
+    uint8_t*  dead;   // literal mode: pixel returned early in this iteration (primary miss)
+    unsigned long long* stats;  // [0] rays traced
+};
+
+PRT_DEV uint32_t wave_push(bool pred, uint32_t* counter)
+{
+    const unsigned long long mask = __ballot(pred);
+    const uint32_t           n    = (uint32_t)__popcll(mask);
+    const int                lane = threadIdx.x & 63;
+    uint32_t                 base = 0;
+    if(n)
+    {
+        const int leader = __ffsll((long long)mask) - 1;
+        if(lane == leader) base = atomicAdd(counter, n);
+        base = (uint32_t)__shfl((int)base, leader, 64);
+    }
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+PRT_DEV uint32_t wave_fetch(uint32_t* workCtr)
+{
+    uint32_t base = 0;
+    if((threadIdx.x & 63) == 0) base = atomicAdd(workCtr, 64u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+}
+
+PRT_DEV void count_rays(const FrameView& f, bool active)
+{
+    const unsigned long long mask = __ballot(active);
+    if((threadIdx.x & 63) == 0 && mask) atomicAdd(f.stats, (unsigned long long)__popcll(mask));
+}
+
+// ---------------------------------------------------------------------------------------------
+// generate — pathRT.rgen:624-690
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_generate(SceneView sc, FrameView f, const prt_uniforms* __restrict__ ubo,
+                                                  uint32_t flags, uint32_t aa)
+{
+    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x;
+    if(px >= f.npix) return;
+    const bool literal = (flags & PRT_FLAG_LITERAL) != 0;
+    if(aa == 0)
+    {
+        if(literal && !(ubo->iteration > 1u)) f.accum[px] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        f.dead[px] = 0;
+    }
+    else if(f.dead[px])
+    {
+        f.rayO[px] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        f.rayD[px] = make_float4(0.0f, 0.0f, 1.0f, -1.0f);  // empty interval: traces as a miss
+        return;
+    }
+    const uint32_t x = px % f.w, y = px / f.w;
+    const uint32_t s0 = scramble_value(sc.scrTable, f.npix, sc.seed, px, 0);
+    const uint32_t s1 = scramble_value(sc.scrTable, f.npix, sc.seed, px, 1);
+    const uint32_t sobolIndex = s0 / 2u + ubo->iteration + aa;
+    f2 off;
+    off.x = sobol1D(sc.sobol, sobolIndex, 2u, s0);
+    off.y = sobol1D(sc.sobol, sobolIndex, 3u, s1);
+    f3 Ro, Rd;
+    if(ubo->numAArays == 1)
+    {
+        off.x = off.x * 2.0f - 1.0f;
+        off.y = off.y * 2.0f - 1.0f;
+        off.x = off.x * ubo->filterRadius;
+        off.y = off.y * ubo->filterRadius;
+        primary_ray(ubo->projViewInverse, x, y, f.w, f.h, off.x + 0.5f, off.y + 0.5f, Ro, Rd);
+    }
+    else
+    {
+        primary_ray(ubo->projViewInverse, x, y, f.w, f.h, off.x, off.y, Ro, Rd);
+        f.aaOff[px] = make_float2(off.x, off.y);
+    }
+    f.rayO[px] = make_float4(Ro.x, Ro.y, Ro.z, 0.000001f);
+    f.rayD[px] = make_float4(Rd.x, Rd.y, Rd.z, 1.0f);
+    f.thr[px]  = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+}
+
+// AO.rgen:185-205 — pixel-centre primary ray, tmin 1e-5
+__global__ void __launch_bounds__(256) k_ao_generate(FrameView f, const prt_uniforms* __restrict__ ubo, uint32_t flags)
+{
+    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x;
+    if(px >= f.npix) return;
+    if((flags & PRT_FLAG_LITERAL) && !(ubo->iteration > 1u)) f.accum[px] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    f3 Ro, Rd;
+    primary_ray(ubo->projViewInverse, px % f.w, px / f.w, f.w, f.h, 0.5f, 0.5f, Ro, Rd);
+    f.rayO[px] = make_float4(Ro.x, Ro.y, Ro.z, 0.00001f);
+    f.rayD[px] = make_float4(Rd.x, Rd.y, Rd.z, 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// extend — closest hit for every queued ray. queue == nullptr: identity (all pixels).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_extend(SceneView sc, FrameView f, const uint32_t* __restrict__ queue,
+                                                            const uint32_t* __restrict__ countPtr,
+                                                            uint32_t* workCtr, uint32_t primary)
+{
+    __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
+    const uint32_t      count = countPtr ? *countPtr : f.npix;
+    const int           lane  = threadIdx.x & 63;
+    for(;;)
+    {
+        const uint32_t base = wave_fetch(workCtr);
+        if(base >= count) break;
+        const uint32_t i      = base + lane;
+        bool           active = i < count;
+        if(active)
+        {
+            const uint32_t px = queue ? queue[i] : i;
+            const float4   o = f.rayO[px], d = f.rayD[px];
+            const Hit      h = trace_ray<false>(sc.bvh, &stackLds[threadIdx.x], mk3(o.x, o.y, o.z), o.w,
+                                                mk3(d.x, d.y, d.z), d.w);
+            f.hit[px] = make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t);
+            if(primary) f.hitIds[px] = h.prim;
+            active = !(d.w < 0.0f);  // placeholder rays of pixels that already returned are not counted
+        }
+        count_rays(f, active);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shade — pathRT.rgen:699-961 for one path vertex
+// ---------------------------------------------------------------------------------------------
+struct VertexU
+{
+    f3      pos, normal;
+    f2      uv;
+    int32_t mat;
+};
+PRT_DEV VertexU load_vertex(const prt_vertex* __restrict__ verts, uint32_t index)
+{
+    const float4* q  = (const float4*)(verts + index);  // 48-byte records, 16-byte aligned
+    const float4  d0 = q[0], d1 = q[1], d2 = q[2];
+    VertexU       v;
+    v.pos    = mk3(d0.x, d0.y, d0.z);
+    v.normal = mk3(d0.w, d1.x, d1.y);
+    v.uv.x   = d1.z;
+    v.uv.y   = d1.w;
+    v.mat    = __float_as_int(d2.w);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const prt_uniforms* __restrict__ ubo,
+                                               uint32_t flags, uint32_t bounce, const uint32_t* __restrict__ queueIn,
+                                               const uint32_t* __restrict__ countIn, uint32_t* __restrict__ queueNext,
+                                               uint32_t* countNext, uint32_t* __restrict__ queueShadow,
+                                               uint32_t* countShadow)
+{
+    const uint32_t count      = countIn ? *countIn : f.npix;
+    const uint32_t lane       = threadIdx.x & 63;
+    const uint32_t waveId     = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t waveCount  = (gridDim.x * blockDim.x) >> 6;
+    const bool     literal    = (flags & PRT_FLAG_LITERAL) != 0;
+    const bool     rr         = (flags & PRT_FLAG_RUSSIAN_ROULETTE) != 0;
+    const int      maxBounces = ubo->numIndirectBounces;
+    const int      numAA      = ubo->numAArays;
+
+    for(uint32_t base = waveId * 64u; base < count; base += waveCount * 64u)
+    {
+        const uint32_t i       = base + lane;
+        bool           shadowQ = false, nextQ = false;
+        uint32_t       px      = 0;
+        if(i < count)
+        {
+            px                 = queueIn ? queueIn[i] : i;
+            const float4   hq  = f.hit[px];
+            const uint32_t primitiveID = (uint32_t)__float_as_int(hq.x);
+            const bool     isDead      = (bounce == 0) && f.dead[px];
+            if(primitiveID == 0xffffffffu || isDead)
+            {
+                if(bounce == 0 && !isDead)
+                {
+                    // primary miss — pathRT.rgen:693-697
+                    const uint32_t x = px % f.w, y = px / f.w;
+                    const float    u = ((float)x + 0.5f) / (float)f.w, v = ((float)y + 0.5f) / (float)f.h;
+                    if(literal)
+                    {
+                        f.accum[px] = make_float4(u, v, 0.4f, 1.0f);
+                        f.dead[px]  = 1;
+                    }
+                    else
+                    {
+                        const float4 E = f.accum[px];
+                        f.accum[px]    = make_float4(E.x + u, E.y + v, E.z + 0.4f, E.w + 1.0f);
+                        f.dead[px]     = 1;
+                    }
+                }
+            }
+            else
+            {
+                const float4 rd4 = f.rayD[px];
+                const f3     Rd  = mk3(rd4.x, rd4.y, rd4.z);
+                const float4 th4 = f.thr[px];
+                f3           throughput = mk3(th4.x, th4.y, th4.z);
+                float        p          = th4.w;
+                const f3     bary       = mk3(1.0f - hq.y - hq.z, hq.y, hq.z);  // pathRT.rchit:19
+
+                // sobolIndex = layer0 / 2 + iteration, +1 per finished aaRay (:627-631, :970); the aaRay
+                // ordinal travels in bits 8..15 of `flags`.
+                const uint32_t s0   = scramble_value(sc.scrTable, f.npix, sc.seed, px, 0);
+                const uint32_t sidx = s0 / 2u + ubo->iteration + ((flags >> 8) & 0xffu);
+                const uint32_t layer = 1u + bounce;  // scrambleArray[scrambleArrayLayer++], :664,:703
+                const uint32_t scr0  = scramble_value(sc.scrTable, f.npix, sc.seed, px, 2u * layer);
+                const uint32_t scr1  = scramble_value(sc.scrTable, f.npix, sc.seed, px, 2u * layer + 1u);
+                const uint32_t dim   = 4u + 4u * bounce;  // sobolDim after the pixel offset, 4 per vertex
+
+                const VertexU v0 = load_vertex(sc.verts, sc.idx[3u * primitiveID]);
+                const VertexU v1 = load_vertex(sc.verts, sc.idx[3u * primitiveID + 1u]);
+                const VertexU v2 = load_vertex(sc.verts, sc.idx[3u * primitiveID + 2u]);
+                const uint32_t      mi  = (v1.mat >= 0 && (uint32_t)v1.mat < sc.nmats) ? (uint32_t)v1.mat : 0u;
+                const prt_material& mat = sc.mats[mi];
+
+                f3 sNormal = normalize3((v0.normal * bary.x + v1.normal * bary.y) + v2.normal * bary.z);
+                if(dot3(sNormal, Rd) > 0.0f) sNormal = -sNormal;
+                const f3 gNormal  = sNormal;
+                const f3 hitPoint = (v0.pos * bary.x + v1.pos * bary.y) + v2.pos * bary.z;
+
+                f3 albedo   = mk3(mat.diffuse[0], mat.diffuse[1], mat.diffuse[2]);
+                f3 specular = mk3(mat.specular[0], mat.specular[1], mat.specular[2]);
+                f3 textureN = mk3(1.0f);
+                f2 texCoord;
+                texCoord.x = (v0.uv.x * bary.x + v1.uv.x * bary.y) + v2.uv.x * bary.z;
+                texCoord.y = (v0.uv.y * bary.x + v1.uv.y * bary.y) + v2.uv.y * bary.z;
+                const int ntex = (int)sc.ntex;
+                const int tD = mat.diffuseTextureID, tS = mat.specularTextureID, tN = mat.normalTextureID;
+                if(tD >= 0 && tD < ntex) albedo = albedo * texture_rgb(sc.tex[tD], texCoord);
+                if(tS >= 0 && tS < ntex) specular = specular * texture_rgb(sc.tex[tS], texCoord);
+                if(tN >= 0 && tN < ntex)
+                {
+                    textureN = texture_rgb(sc.tex[tN], texCoord) * 2.0f - mk3(1.0f);
+                    // bump mapping — :754-783
+                    const f3    v10 = v1.pos - v0.pos, v20 = v2.pos - v0.pos;
+                    const float u10x = v1.uv.x - v0.uv.x, u10y = v1.uv.y - v0.uv.y;
+                    const float u20x = v2.uv.x - v0.uv.x, u20y = v2.uv.y - v0.uv.y;
+                    const float det  = u10x * u20y - u20x * u10y;
+                    if(gabs(det) > 1e-4f)
+                    {
+                        const float od    = 1.0f / det;
+                        const float c0x = u20y * od, c0y = -u10y * od;
+                        const float c1x = -u20x * od, c1y = u10x * od;
+                        m3 nm;
+                        nm.c0   = normalize3(v10 * c0x + v20 * c0y);
+                        nm.c1   = normalize3(v10 * c1x + v20 * c1y);
+                        nm.c2   = sNormal;
+                        sNormal = mulM(nm, textureN);
+                    }
+                }
+                {
+                    const float mx = maxcoord(albedo + specular);  // :786-793
+                    if(mx > 1.0f)
+                    {
+                        albedo   = albedo / mk3(mx);
+                        specular = specular / mk3(mx);
+                    }
+                }
+
+                // light sample — :798-805, sampleLight :304-309
+                f2 s;
+                s.x = sobol1D(sc.sobol, sidx, dim + 0u, scr0);
+                s.y = sobol1D(sc.sobol, sidx, dim + 1u, scr1);
+                float       pdf = 1.0f / (4.0f * ubo->lightSize[0] * ubo->lightSize[1]);
+                const float lpx = (s.x * 2.0f - 1.0f) * ubo->lightSize[0];
+                const float lpy = (s.y * 2.0f - 1.0f) * ubo->lightSize[1];
+                float       lp[4];
+                mul44(ubo->lightTransform, lpx, lpy, 0.0f, 1.0f, lp);
+                const f3 vLight = mk3(lp[0], lp[1], lp[2]) - hitPoint;
+
+                const float roughness = gclamp(1.0f - mat.shininess, 0.001f, 1.0f);
+                const float alpha     = roughness * roughness;
+                const m3    l2w       = form_basis(gNormal);
+                const f3    wo        = normalize3(mulMT(l2w, -Rd));
+
+                // direct term, evaluated as if the light sample were visible — :824-847
+                f3 EiV;
+                {
+                    const f3    lightNormal = -normalize3(mk3(ubo->lightTransform[8], ubo->lightTransform[9],
+                                                               ubo->lightTransform[10]));
+                    const float r           = length3(vLight);
+                    const float cosL        = gclamp(dot3(normalize3(-vLight), lightNormal), 0.0f, 1.0f);
+                    const float cosS        = gclamp(dot3(sNormal, normalize3(vLight)), 0.0f, 1.0f);
+                    const f3    wiL         = normalize3(mulMT(l2w, vLight));
+                    const f3    wmL         = normalize3(wo + vLight);  // sic (:837)
+                    const f3    F           = ggx_schlick(specular, dot3(wiL, wmL));
+                    const float G1          = ggx_smith_masking(wo, alpha);
+                    const float G2          = ggx_smith_masking_shadowing(wiL, wo, alpha);
+                    const f3    brdf        = F * (G2 / G1);
+                    const f3    lightE      = mk3(ubo->lightE[0], ubo->lightE[1], ubo->lightE[2]);
+                    EiV = mk3(0.0f) + lightE * cosL * cosS / (r * r * pdf);
+                    EiV = EiV * (brdf * throughput);
+                }
+
+                // BSDF sample — :849-918
+                f3 wi           = mk3(0.0f);
+                f3 specularBRDF = mk3(0.0f);
+                {
+                    f2 rnd;
+                    rnd.x       = sobol1D(sc.sobol, sidx, dim + 2u, scr0);
+                    rnd.y       = sobol1D(sc.sobol, sidx, dim + 3u, scr1);
+                    const f3 wm = ggx_sample_vndf(wo, alpha, rnd);
+                    const float fres = ggx_fresnel_dielectric(wo.z, 1.0f, 1.45f);
+                    if(mat.dissolve == 0.0f)
+                    {
+                        if(rnd.x < fres)
+                        {
+                            wi = normalize3(reflect3(-wo, wm));
+                        }
+                        else
+                        {
+                            if(!refract3(wo, mk3(0.0f, 0.0f, 1.0f), wi, 1.0f / 1.45f)) wi = reflect3(-wo, wm);
+                            wi = normalize3(wi);
+                        }
+                    }
+                    else
+                    {
+                        wi = normalize3(reflect3(-wo, wm));
+                    }
+                    if(wi.z > 0.0f)
+                    {
+                        const float D   = ggx_distribution(wm, alpha);
+                        const float G1v = ggx_g1(wo, wm, alpha);
+                        if(mat.dissolve == 1.0f)
+                        {
+                            const f3    F  = ggx_schlick(specular, dot3(wi, wm));
+                            const float G1 = gclamp(ggx_smith_masking(wo, alpha), 1e-4f, 1.0f);
+                            const float G2 = ggx_smith_masking_shadowing(wi, wo, alpha);
+                            specular       = F * G1v;
+                            specularBRDF   = F * (G2 / G1);
+                        }
+                        else
+                        {
+                            pdf          = 1.0f - gclamp(fres, 0.0f, 1.0f - 1e-2f);
+                            specularBRDF = albedo / pdf;
+                        }
+                        p = G1v * gabs(dot3(wm, wi)) * D / wi.z;
+                        p *= 1.0f / (4.0f * gabs(dot3(wo, wm)));
+                    }
+                }
+                wi          = mulM(l2w, wi);
+                const f3 Rn = wi * mk3(1000.0f);
+
+                f3    color  = albedo * 1.0f + specular * specularBRDF;
+                float colorw = 1.0f;
+                if(numAA != 1)
+                {
+                    const float2 ro     = f.aaOff[px];
+                    const float  weight = mitchell_netrevali(ro.x + 0.5f) * mitchell_netrevali(ro.y + 0.5f);
+                    color               = mk3(color.x / weight, color.y / weight, color.z / weight);
+                    colorw              = colorw / weight;
+                }
+
+                // accumulate — :939-942; the shadow kernel picks one of the two and adds it to E
+                const f3 em  = mk3(mat.emission[0], mat.emission[1], mat.emission[2]) * ubo->lightOtherE;
+                const f3 tc  = throughput * color;
+                f3       EiO = mk3(0.0f) + em;
+                EiO          = EiO * tc;
+                EiV          = EiV + em;
+                EiV          = EiV * tc;
+                f.shO[px]    = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, colorw);
+                f.shD[px]    = make_float4(vLight.x, vLight.y, vLight.z, 0.0f);
+                f.eiVis[px]  = make_float4(EiV.x, EiV.y, EiV.z, 0.0f);
+                f.eiOcc[px]  = make_float4(EiO.x, EiO.y, EiO.z, 0.0f);
+                shadowQ      = true;
+
+                // termination — :944-961
+                bool alive = true;
+                if(!(p < 0.0f || p >= 0.0f)) alive = false;
+                if(alive && p == 0.0f) alive = false;
+                if(alive)
+                {
+                    throughput = throughput * color;
+                    if((int)(bounce + 1u) > maxBounces) alive = false;
+                }
+                if(alive && rr && (bounce + 1u) >= 2u)
+                {
+                    // Russian roulette (extension, off by default)
+                    const uint32_t b1  = bounce + 1u;
+                    const uint32_t rs  = scramble_value(sc.scrTable, f.npix, sc.seed, px, 30u + (b1 & 1u));
+                    const float    q   = gclamp(maxcoord(throughput), 0.05f, 1.0f);
+                    const float    xi  = sobol1D(sc.sobol, sidx, 48u + b1, rs);
+                    if(xi >= q)
+                        alive = false;
+                    else
+                        throughput = throughput / mk3(q);
+                }
+                if(alive)
+                {
+                    f.rayO[px] = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, 0.000001f);
+                    f.rayD[px] = make_float4(Rn.x, Rn.y, Rn.z, 1.0f);
+                    f.thr[px]  = make_float4(throughput.x, throughput.y, throughput.z, p);
+                    nextQ      = true;
+                }
+            }
+        }
+        const uint32_t si = wave_push(shadowQ, countShadow);
+        if(shadowQ) queueShadow[si] = px;
+        const uint32_t ni = wave_push(nextQ, countNext);
+        if(nextQ) queueNext[ni] = px;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shadow + connect — traceNV(terminate on first hit) :818-822, then the accumulation of :939-942
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_shadow(SceneView sc, FrameView f,
+                                                            const uint32_t* __restrict__ queue,
+                                                            const uint32_t* __restrict__ countPtr, uint32_t* workCtr)
+{
+    __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
+    const uint32_t      count = *countPtr;
+    const int           lane  = threadIdx.x & 63;
+    for(;;)
+    {
+        const uint32_t base = wave_fetch(workCtr);
+        if(base >= count) break;
+        const uint32_t i      = base + lane;
+        const bool     active = i < count;
+        if(active)
+        {
+            const uint32_t px = queue[i];
+            const float4   o = f.shO[px], d = f.shD[px];
+            const Hit      h = trace_ray<true>(sc.bvh, &stackLds[threadIdx.x], mk3(o.x, o.y, o.z), 0.000001f,
+                                               mk3(d.x, d.y, d.z), 1.0f);
+            const float4   Ei = (h.prim != 0xffffffffu) ? f.eiOcc[px] : f.eiVis[px];
+            const float4   E  = f.accum[px];
+            f.accum[px]       = make_float4(E.x + Ei.x, E.y + Ei.y, E.z + Ei.z, E.w + o.w);
+        }
+        count_rays(f, active);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// AO — AO.rgen:214-272, after k_ao_generate + k_extend
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, FrameView f,
+                                                              const prt_uniforms* __restrict__ ubo, uint32_t flags,
+                                                              uint32_t* workCtr)
+{
+    __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
+    const uint32_t      count   = f.npix;
+    const int           lane    = threadIdx.x & 63;
+    const bool          literal = (flags & PRT_FLAG_LITERAL) != 0;
+    const int           numAO   = ubo->numAOrays;
+    const float         aoLen   = ubo->aoRayLength;
+    for(;;)
+    {
+        const uint32_t base = wave_fetch(workCtr);
+        if(base >= count) break;
+        const uint32_t px = base + lane;
+        if(px < count)
+        {
+            const float4   hq   = f.hit[px];
+            const uint32_t prim = (uint32_t)__float_as_int(hq.x);
+            const float4   E    = f.accum[px];
+            if(prim == 0xffffffffu)
+            {
+                f.accum[px] = literal ? make_float4(0.1f, 0.1f, 0.1f, 0.0f)
+                                      : make_float4(E.x + 0.1f, E.y + 0.1f, E.z + 0.1f, E.w + 0.0f);
+            }
+            else
+            {
+                const uint32_t scr0 = scramble_value(sc.scrTable, f.npix, sc.seed, px, 0);
+                const uint32_t scr1 = scramble_value(sc.scrTable, f.npix, sc.seed, px, 1);
+                uint32_t sobolIndex = scramble_value(sc.scrTable, f.npix, sc.seed, px, 2);
+                const VertexU v0 = load_vertex(sc.verts, sc.idx[3u * prim]);
+                const VertexU v1 = load_vertex(sc.verts, sc.idx[3u * prim + 1u]);
+                const VertexU v2 = load_vertex(sc.verts, sc.idx[3u * prim + 2u]);
+                const f3      bary = mk3(1.0f - hq.y - hq.z, hq.y, hq.z);
+                const float4  rd4  = f.rayD[px];
+                f3 normal = normalize3((v0.normal * bary.x + v1.normal * bary.y) + v2.normal * bary.z);
+                if(dot3(normal, mk3(rd4.x, rd4.y, rd4.z)) > 0.0f) normal = normal * -1.0f;
+                const m3 onb      = form_basis(normal);
+                f3       hitPoint = (v0.pos * bary.x + v1.pos * bary.y) + v2.pos * bary.z;
+                hitPoint          = hitPoint + 0.0001f * normal;
+                int noHit = 0;
+                for(int k = 0; k < numAO; ++k)
+                {
+                    // hemisphereSample — AO.rgen:153-181
+                    const float s0 = sobol1D(sc.sobol, sobolIndex, 0u, scr0);
+                    const float s1 = sobol1D(sc.sobol, sobolIndex, 1u, scr1);
+                    sobolIndex++;
+                    float       phi, r;
+                    const float a = 2.0f * s0 - 1.0f;
+                    const float b = 2.0f * s1 - 1.0f;
+                    if(a * a > b * b)
+                    {
+                        r   = a;
+                        phi = kPi * 0.25f * (b / a);
+                    }
+                    else
+                    {
+                        r   = b;
+                        phi = kPi * 0.5f - kPi * 0.25f * (a / b);
+                    }
+                    float sn, cs;
+                    sincos_fixed(phi, sn, cs);
+                    const float hx = r * cs;
+                    const float hy = r * sn;
+                    const float hz = __builtin_sqrtf(gmax(0.0f, 1.0f - hx * hx - hy * hy));
+                    const f3    Rd = normalize3(mulM(onb, mk3(hx, hy, hz))) * mk3(aoLen);
+                    const Hit   h  = trace_ray<true>(sc.bvh, &stackLds[threadIdx.x], hitPoint, 0.00001f, Rd, 1.0f);
+                    if(h.prim == 0xffffffffu) noHit++;
+                }
+                atomicAdd(f.stats, (unsigned long long)numAO);
+                const float ao = (float)noHit / (float)numAO;
+                f.accum[px]    = make_float4(E.x + ao, E.y + ao, E.z + ao, E.w + 1.0f);
+            }
+        }
+    }
+}
+
+// pathRTpostprocess.comp:38-51 over the whole image (the reference's W/16 x H/16 dispatch drops
+// edge pixels when W,H are not multiples of 16, vkRTX_setup.cpp:779).
+__global__ void __launch_bounds__(256) k_postprocess(const float4* __restrict__ accum, uint32_t npix,
+                                                     uint32_t* __restrict__ rgba8)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= npix) return;
+    float4 c = accum[i];
+    if(c.w != 0.0f)
+    {
+        c.x /= c.w;
+        c.y /= c.w;
+        c.z /= c.w;
+        c.w /= c.w;
+    }
+    c.x = __powf(c.x, 1.0f / 2.2f);
+    c.y = __powf(c.y, 1.0f / 2.2f);
+    c.z = __powf(c.z, 1.0f / 2.2f);
+    const float v[4] = {c.x, c.y, c.z, c.w};
+    uint32_t    out  = 0;
+    for(int k = 0; k < 4; ++k)
+    {
+        float t = v[k];
+        t       = !(t > 0.0f) ? 0.0f : (t > 1.0f ? 1.0f : t);
+        out |= (uint32_t)(t * 255.0f + 0.5f) << (8 * k);
+    }
+    rgba8[i] = out;
+}
+
+// generic batch trace for prt_trace() (unit tests / ray-level benchmarks)
+template <bool ANY>
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_trace_batch(BvhView bvh, const float4* __restrict__ rays,
+                                                                 uint32_t n, float4* __restrict__ hits)
+{
+    __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
+    const uint32_t      i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n) return;
+    const float4 o = rays[2 * i], d = rays[2 * i + 1];
+    const Hit    h = trace_ray<ANY>(bvh, &stackLds[threadIdx.x], mk3(o.x, o.y, o.z), o.w, mk3(d.x, d.y, d.z), d.w);
+    hits[i]        = make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t);
+}
+
+}  // namespace prt
