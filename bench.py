@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json metric: Mrays/s (whole job, primary + bounce + shadow rays) on the conference
+workload, 1920x1080, path tracing, 5 bounces, GGX + area-light NEE.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one progressive iteration (1 sample per pixel over the whole image) per GPU. With N > 1 the
+scene is replicated, rank r renders iterations r+1, r+1+N, ... (sample sharding) into its own
+float4 buffer and the buffers are summed with one RCCL all-reduce inside the timed region ("weak" scaling:
+K iterations per GPU whatever N is). Inputs (scene, BVH, uniforms) are resident in HBM before timing starts.
+
+One JSON line on stdout (rank 0). `roofline` is for the dominant kernel (closest-hit or any-hit traversal):
+algorithmic bytes per ray x rays per launch / mean launch duration from HIP events recorded on the
+library's stream during the timed region. `cpu_baseline` is the CPU oracle (oracle/, a port of the reference
+shaders — the reference has no CPU path) timed on this host on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bounces", type=int, default=5)
+    ap.add_argument("--detail", type=float, default=1.4, help="scene tessellation (1.4 = ~330k triangles)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-profile", action="store_true", help="skip per-kernel event timing (roofline = null)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        log(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}")
+    n_gpus = world
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    from pathtracer_amd import capi, scenes, uniforms
+
+    W, H, K, WU = args.width, args.height, args.steps, args.warmup
+    t0 = time.time()
+    scene = scenes.conference_room(seed=2, detail=args.detail)
+    ntri = len(scene["indices"]) // 3
+    ctx = capi.Context(W, H, device=local)
+    ctx.set_scene(scene)
+    ctx.set_seed(2)
+    ctx.build_accel()
+    st = ctx.stats()
+    if rank == 0:
+        log(f"[bench] scene {scene['name']}: {ntri} triangles, BVH {st.bvh_nodes} nodes depth {st.bvh_depth} "
+            f"built on GPU in {st.bvh_build_ms:.1f} ms (setup {time.time() - t0:.1f} s)")
+    ubo = uniforms.make_uniforms(scene, W, H, bounces=args.bounces, spp=1024, iteration=1)
+    ctx.set_uniforms(ubo)
+    ctx.set_flags(0)  # additive accumulation: required for the multi-GPU sum
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
+    ctx.bind_accum(accum.data_ptr())
+
+    # instrumented pass (untimed): mean nodes fetched / triangles tested per ray for the bytes formula
+    n_node = n_tri = None
+    prof2 = None
+    if not args.no_profile:
+        ctx.set_profiling(2)
+        ctx.reset_stats()
+        ctx.render(capi.MODE_PATH, 1 + rank, 2, n_gpus)
+        prof2 = ctx.profile()
+        ctx.set_profiling(1)
+    # warmup
+    ctx.render(capi.MODE_PATH, 1 + rank, WU, n_gpus)
+    ctx.sync()
+    accum.zero_()
+    torch.cuda.synchronize()
+    ctx.reset_stats()
+
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    ctx.render(capi.MODE_PATH, 1 + rank, K, n_gpus)
+    ctx.sync()
+    if dist:
+        dist.all_reduce(accum, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+
+    stats = ctx.stats()
+    rays = torch.tensor([float(stats.rays)], dtype=torch.float64, device=f"cuda:{local}")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+    if dist:
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_rays = float(rays.item())
+    elapsed = float(tmax.item())
+    finite = bool(torch.isfinite(accum[..., 3]).all().item())
+
+    roofline = None
+    kernels = {}
+    if not args.no_profile:
+        p = ctx.profile()
+        for k, name in capi.KERNEL_NAMES.items():
+            if p.launches[k]:
+                kernels[name] = {"ms_total": round(p.ms[k], 3), "launches": int(p.launches[k]),
+                                 "ms_per_launch": round(p.ms[k] / p.launches[k], 4)}
+        cn = prof2.closest_nodes / max(1, prof2.closest_rays)
+        ct = prof2.closest_tris / max(1, prof2.closest_rays)
+        an = prof2.any_nodes / max(1, prof2.any_rays)
+        at = prof2.any_tris / max(1, prof2.any_rays)
+        # B_ray = 32 + 32 (ray record w+r) + 16 + 16 (hit w+r) + N_node*64 + N_tri*48
+        b_closest = 96.0 + cn * 64.0 + ct * 48.0
+        b_any = 96.0 + an * 64.0 + at * 48.0
+        if p.ms[capi.K_EXTEND] >= p.ms[capi.K_SHADOW]:
+            kind, kname, b_ray, nrays = capi.K_EXTEND, "k_extend (closest-hit traversal)", b_closest, p.closest_rays
+            nn, nt = cn, ct
+        else:
+            kind, kname, b_ray, nrays = capi.K_SHADOW, "k_shadow (any-hit traversal + accumulate)", b_any, p.any_rays
+            nn, nt = an, at
+        launches = max(1, int(p.launches[kind]))
+        ms_launch = p.ms[kind] / launches
+        bytes_launch = b_ray * nrays / launches
+        achieved = bytes_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(kname.split(" ")[0], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(nn, 2), "tris_per_ray": round(nt, 2),
+                    "rays_per_launch": round(nrays / launches, 1), "ms_per_launch": round(ms_launch, 4),
+                    "launches": launches,
+                    "other": {"closest": {"nodes_per_ray": round(cn, 2), "tris_per_ray": round(ct, 2)},
+                              "any": {"nodes_per_ray": round(an, 2), "tris_per_ray": round(at, 2)}}}
+
+    cpu_baseline = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import pyoracle as po
+
+            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            orc = po.Oracle(scene, seed=2)
+            orc.build_bvh()
+            t1 = time.perf_counter()
+            _, _, crays = orc.render(ubo, W, H, 0, flags=0, threads=threads)
+            dt = time.perf_counter() - t1
+            cpu_baseline = {"value": round(crays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                            "sample": f"1 iteration (1 spp, {crays} rays) of the same {W}x{H} conference workload, "
+                                      f"{dt:.1f} s, oracle/liboracle.so"}
+        except Exception as e:  # the baseline is a report, never a dependency of the GPU path
+            cpu_baseline = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+    if rank == 0:
+        value = total_rays / elapsed / 1e6
+        out = {
+            "metric": "Mrays/s (whole node, incl. secondary) conference 1080p",
+            "value": round(value, 2),
+            "unit": "Mrays/s",
+            "n_gpus": n_gpus,
+            "steps": K,
+            "warmup": WU,
+            "ms_per_step": round(elapsed / K * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (procedural conference-scale scene, seed 2; the reference's scenes are not in its repo)",
+            "config": {"workload": f"conference-scale room, {ntri} triangles, {W}x{H}, path tracing, "
+                                   f"{args.bounces} bounces, GGX + area-light NEE, 1 spp per step",
+                       "triangles": ntri, "width": W, "height": H, "bounces": args.bounces,
+                       "iterations_per_gpu": K, "parallelism": f"spp-sharded x{n_gpus}" if n_gpus > 1 else "single GPU",
+                       "rays_total": int(total_rays), "rays_per_sample": round(total_rays / (K * n_gpus * W * H), 3),
+                       "bvh_build_ms": round(st.bvh_build_ms, 2), "image_finite": finite},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "kernels": kernels,
+        }
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

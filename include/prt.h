@@ -72,6 +72,23 @@ typedef struct prt_stats
     float    bvh_build_ms;    /* wall time of the last prt_build_accel */
 } prt_stats;
 
+/* Kernel kinds of prt_profile */
+#define PRT_K_GENERATE 0
+#define PRT_K_EXTEND 1   /* closest-hit traversal (traceNV, pathRT.rgen:692,963) */
+#define PRT_K_SHADE 2
+#define PRT_K_SHADOW 3   /* any-hit traversal + accumulate (pathRT.rgen:818-822, 939-942) */
+#define PRT_K_AO_SHADE 4 /* AO.rgen:222-272 */
+#define PRT_K_COUNT 8
+
+typedef struct prt_profile
+{
+    double   ms[PRT_K_COUNT];       /* summed kernel time per kind, HIP events on the context's stream */
+    uint64_t launches[PRT_K_COUNT];
+    uint64_t closest_rays, any_rays;
+    uint64_t closest_nodes, closest_tris; /* 64-byte nodes fetched / triangles tested by closest-hit rays */
+    uint64_t any_nodes, any_tris;         /* ... by any-hit rays (both only at profiling level 2) */
+} prt_profile;
+
 /* VkRTX::VkRTX(ctx, extent) — vkRTX_setup.h:20-24. Binds to HIP device `device_ordinal`. */
 int prt_create(int device_ordinal, uint32_t width, uint32_t height, prt_context** out);
 /* VkRTX::cleanUp — vkRTX_setup.h:40, vkRTX_setup.cpp:913-1032 */
@@ -123,6 +140,11 @@ int prt_postprocess(prt_context* ctx, uint8_t* rgba8_out);
 int prt_read_hit_ids(prt_context* ctx, uint32_t* ids_out);
 int prt_get_stats(prt_context* ctx, prt_stats* out); /* synchronous */
 int prt_reset_stats(prt_context* ctx);
+/* The reference has no profiling hooks. level 0: off; 1: bracket every kernel launch with HIP
+ * events on the context's stream; 2: additionally run the traversal kernels in their instrumented form that
+ * counts node fetches and triangle tests. prt_get_profile is synchronous; totals since prt_reset_stats. */
+int prt_set_profiling(prt_context* ctx, int level);
+int prt_get_profile(prt_context* ctx, prt_profile* out);
 
 /* traceNV for a batch of host rays (closest hit, or any_hit != 0 for the terminate-on-first-hit
  * occlusion query of pathRT.rgen:819-822). Synchronous; for tests and ray-level measurements. */

@@ -22,13 +22,23 @@ EXPORTS = [
     "prt_upload_scrambles", "prt_set_uniforms", "prt_set_flags", "prt_render_iteration", "prt_render", "prt_sync",
     "prt_clear_accum", "prt_read_accum", "prt_device_accum_ptr", "prt_bind_accum", "prt_postprocess",
     "prt_read_hit_ids", "prt_get_stats", "prt_reset_stats", "prt_trace", "prt_trace_device", "prt_read_bvh",
-    "prt_read_sobol",
+    "prt_read_sobol", "prt_set_profiling", "prt_get_profile",
 ]
+
+K_GENERATE, K_EXTEND, K_SHADE, K_SHADOW, K_AO_SHADE, K_COUNT = 0, 1, 2, 3, 4, 8
+KERNEL_NAMES = {K_GENERATE: "generate", K_EXTEND: "extend", K_SHADE: "shade", K_SHADOW: "shadow",
+                K_AO_SHADE: "ao_shade"}
 
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("iterations", C.c_uint64), ("bvh_nodes", C.c_uint32),
                 ("bvh_inner_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("bvh_build_ms", C.c_float)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8), ("closest_rays", C.c_uint64),
+                ("any_rays", C.c_uint64), ("closest_nodes", C.c_uint64), ("closest_tris", C.c_uint64),
+                ("any_nodes", C.c_uint64), ("any_tris", C.c_uint64)]
 
 
 class _Tex(C.Structure):
@@ -75,6 +85,8 @@ def lib():
         L.prt_trace_device.argtypes = [vp, vp, sz, i32, vp, C.POINTER(C.c_float)]
         L.prt_read_bvh.argtypes = [vp, vp, vp]
         L.prt_read_sobol.argtypes = [vp, vp]
+        L.prt_set_profiling.argtypes = [vp, i32]
+        L.prt_get_profile.argtypes = [vp, C.POINTER(Profile)]
         for name in EXPORTS:
             if name != "prt_last_error":
                 getattr(L, name).restype = i32
@@ -196,6 +208,14 @@ class Context:
 
     def reset_stats(self):
         self._chk(self.L.prt_reset_stats(self.h_))
+
+    def set_profiling(self, level):
+        self._chk(self.L.prt_set_profiling(self.h_, level))
+
+    def profile(self):
+        p = Profile()
+        self._chk(self.L.prt_get_profile(self.h_, C.byref(p)))
+        return p
 
     # -- inspection --------------------------------------------------------------------------
     def trace(self, rays, any_hit=False):

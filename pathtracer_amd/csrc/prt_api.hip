@@ -66,7 +66,21 @@ struct prt_context
     uint32_t*           counters = nullptr;  // kCounterWords per pass
     unsigned long long* stats    = nullptr;
     uint64_t            iterations = 0;
+
+    // profiling
+    int profLevel = 0;
+    struct Pending
+    {
+        int        kind;
+        hipEvent_t e0, e1;
+    };
+    std::vector<Pending>    pending;
+    std::vector<hipEvent_t> eventPool;
+    double                  profMs[PRT_K_COUNT]       = {};
+    uint64_t                profLaunches[PRT_K_COUNT] = {};
 };
+
+static constexpr uint32_t kStatWords = 8;
 
 static constexpr uint32_t kUboRing      = 64;
 static constexpr uint32_t kCounterWords = 256;
@@ -106,6 +120,8 @@ static void dfree(T*& p)
     p = nullptr;
 }
 static inline uint32_t cdiv(size_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+static void prof_collect(prt_context* c);
 
 static void free_scene(prt_context* c)
 {
@@ -162,7 +178,7 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
     if(e == hipSuccess) e = dalloc(c->q[1], n);
     if(e == hipSuccess) e = dalloc(c->qShadow, n);
     if(e == hipSuccess) e = dalloc(c->counters, (size_t)kCounterWords);
-    if(e == hipSuccess) e = dalloc(c->stats, (size_t)4);
+    if(e == hipSuccess) e = dalloc(c->stats, (size_t)kStatWords);
     if(e == hipSuccess) e = dalloc(c->dUbo, (size_t)kUboRing);
     if(e == hipSuccess) e = hipHostMalloc((void**)&c->hUbo, kUboRing * sizeof(prt_uniforms), hipHostMallocDefault);
     if(e == hipSuccess) e = dalloc(c->dSobol, (size_t)64 * 32);
@@ -173,7 +189,7 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
         e = hipMemcpy(c->dSobol, tbl, sizeof tbl, hipMemcpyHostToDevice);
     }
     if(e == hipSuccess) e = hipMemset(c->accumOwn, 0, n * sizeof(float4));
-    if(e == hipSuccess) e = hipMemset(c->stats, 0, 4 * sizeof(unsigned long long));
+    if(e == hipSuccess) e = hipMemset(c->stats, 0, kStatWords * sizeof(unsigned long long));
     if(e == hipSuccess) e = hipMemset(c->dead, 0, n);
     if(e == hipSuccess) e = hipMemset(c->hitIds, 0xff, n * 4);
     if(e != hipSuccess)
@@ -222,6 +238,8 @@ int prt_destroy(prt_context* c)
     if(c->hUbo) (void)hipHostFree(c->hUbo);
     dfree(c->dSobol);
     dfree(c->dScramble);
+    prof_collect(c);
+    for(hipEvent_t e : c->eventPool) (void)hipEventDestroy(e);
     if(c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PRT_OK;
@@ -461,6 +479,60 @@ int prt_set_flags(prt_context* c, uint32_t flags)
     return PRT_OK;
 }
 
+static hipEvent_t prof_event(prt_context* c)
+{
+    if(!c->eventPool.empty())
+    {
+        hipEvent_t e = c->eventPool.back();
+        c->eventPool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+static void prof_collect(prt_context* c)
+{
+    if(c->pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for(auto& p : c->pending)
+    {
+        float ms = 0.0f;
+        if(hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess)
+        {
+            c->profMs[p.kind] += ms;
+            c->profLaunches[p.kind]++;
+        }
+        c->eventPool.push_back(p.e0);
+        c->eventPool.push_back(p.e1);
+    }
+    c->pending.clear();
+}
+// brackets one launch with events when profiling is on
+struct ProfScope
+{
+    prt_context* c;
+    int          kind;
+    hipEvent_t   e0 = nullptr;
+    ProfScope(prt_context* c_, int k) : c(c_), kind(k)
+    {
+        if(c->profLevel > 0)
+        {
+            e0 = prof_event(c);
+            (void)hipEventRecord(e0, c->stream);
+        }
+    }
+    ~ProfScope()
+    {
+        if(e0)
+        {
+            hipEvent_t e1 = prof_event(c);
+            (void)hipEventRecord(e1, c->stream);
+            c->pending.push_back({kind, e0, e1});
+        }
+    }
+};
+
 static void make_views(prt_context* c, SceneView& sc, FrameView& f)
 {
     sc.verts        = c->dVerts;
@@ -495,6 +567,17 @@ static void make_views(prt_context* c, SceneView& sc, FrameView& f)
     f.stats         = c->stats;
 }
 
+static void launch_extend(prt_context* c, const SceneView& sc, const FrameView& f, uint32_t grid, const uint32_t* q,
+                          const uint32_t* n, uint32_t* work, uint32_t primary)
+{
+    ProfScope ps(c, PRT_K_EXTEND);
+    if(c->profLevel >= 2)
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc, f, q, n, work, primary);
+    else
+        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc, f, q, n, work,
+                           primary);
+}
+
 // One vkCmdTraceRaysNV(W,H,1): a fixed launch sequence, no host synchronisation.
 static int render_one(prt_context* c, int mode)
 {
@@ -519,11 +602,16 @@ static int render_one(prt_context* c, int mode)
     if(mode == PRT_MODE_AO)
     {
         HIPCHK(c, hipMemsetAsync(c->counters, 0, kCounterWords * 4, st));
-        hipLaunchKernelGGL(k_ao_generate, dim3(gridPix), dim3(256), 0, st, f, (const prt_uniforms*)dU, c->flags);
-        hipLaunchKernelGGL(k_extend, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, c->counters + 0, 1u);
-        hipLaunchKernelGGL(k_ao_shade, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, (const prt_uniforms*)dU,
-                           c->flags, c->counters + 1);
+        {
+            ProfScope ps(c, PRT_K_GENERATE);
+            hipLaunchKernelGGL(k_ao_generate, dim3(gridPix), dim3(256), 0, st, f, (const prt_uniforms*)dU, c->flags);
+        }
+        launch_extend(c, sc, f, gridTrace, nullptr, nullptr, c->counters + 0, 1u);
+        {
+            ProfScope ps(c, PRT_K_AO_SHADE);
+            hipLaunchKernelGGL(k_ao_shade, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+                               (const prt_uniforms*)dU, c->flags, c->counters + 1);
+        }
         HIPCHK(c, hipGetLastError());
         c->iterations++;
         return PRT_OK;
@@ -535,20 +623,35 @@ static int render_one(prt_context* c, int mode)
         //           [64..127] work-fetch cursors of the extend launches, [128..191] of the shadow launches
         HIPCHK(c, hipMemsetAsync(c->counters, 0, kCounterWords * 4, st));
         const uint32_t fl = c->flags | ((uint32_t)aa << 8);
-        hipLaunchKernelGGL(k_generate, dim3(gridPix), dim3(256), 0, st, sc, f, (const prt_uniforms*)dU, c->flags,
-                           (uint32_t)aa);
+        {
+            ProfScope ps(c, PRT_K_GENERATE);
+            hipLaunchKernelGGL(k_generate, dim3(gridPix), dim3(256), 0, st, sc, f, (const prt_uniforms*)dU, c->flags,
+                               (uint32_t)aa);
+        }
         for(int b = 0; b <= B; ++b)
         {
             const uint32_t* qIn  = b == 0 ? nullptr : c->q[b & 1];
             const uint32_t* nIn  = b == 0 ? nullptr : c->counters + b;
             uint32_t*       qOut = c->q[(b + 1) & 1];
-            hipLaunchKernelGGL(k_extend, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, qIn, nIn,
-                               c->counters + 64 + b, b == 0 ? 1u : 0u);
-            hipLaunchKernelGGL(k_shade, dim3(gridShade), dim3(256), 0, st, sc, f, (const prt_uniforms*)dU, fl,
-                               (uint32_t)b, qIn, nIn, qOut, c->counters + b + 1, c->qShadow, c->counters + 32 + b);
-            hipLaunchKernelGGL(k_shadow, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                               (const uint32_t*)c->qShadow, (const uint32_t*)(c->counters + 32 + b),
-                               c->counters + 128 + b);
+            launch_extend(c, sc, f, gridTrace, qIn, nIn, c->counters + 64 + b, b == 0 ? 1u : 0u);
+            {
+                ProfScope ps(c, PRT_K_SHADE);
+                hipLaunchKernelGGL(k_shade, dim3(gridShade), dim3(256), 0, st, sc, f, (const prt_uniforms*)dU, fl,
+                                   (uint32_t)b, qIn, nIn, qOut, c->counters + b + 1, c->qShadow,
+                                   c->counters + 32 + b);
+            }
+            {
+                ProfScope ps(c, PRT_K_SHADOW);
+                if(c->profLevel >= 2)
+                    hipLaunchKernelGGL(k_shadow<true>, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+                                       (const uint32_t*)c->qShadow, (const uint32_t*)(c->counters + 32 + b),
+                                       c->counters + 128 + b);
+                else
+                    hipLaunchKernelGGL(k_shadow<false>, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+                                       (const uint32_t*)c->qShadow, (const uint32_t*)(c->counters + 32 + b),
+                                       c->counters + 128 + b);
+            }
+            if(c->pending.size() > 8192) prof_collect(c);
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -648,10 +751,10 @@ int prt_get_stats(prt_context* c, prt_stats* s)
 {
     if(!c || !s) return PRT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    unsigned long long rays = 0;
-    HIPCHK(c, hipMemcpyAsync(&rays, c->stats, 8, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long rays[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(rays, c->stats, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    s->rays            = rays;
+    s->rays            = rays[0] + rays[1];
     s->iterations      = c->iterations;
     s->bvh_nodes       = c->nNodes;
     s->bvh_inner_nodes = c->nInner;
@@ -664,8 +767,45 @@ int prt_reset_stats(prt_context* c)
 {
     if(!c) return PRT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemsetAsync(c->stats, 0, 4 * sizeof(unsigned long long), c->stream));
+    prof_collect(c);
+    HIPCHK(c, hipMemsetAsync(c->stats, 0, kStatWords * sizeof(unsigned long long), c->stream));
     c->iterations = 0;
+    for(int k = 0; k < PRT_K_COUNT; ++k)
+    {
+        c->profMs[k]       = 0.0;
+        c->profLaunches[k] = 0;
+    }
+    return PRT_OK;
+}
+
+int prt_set_profiling(prt_context* c, int level)
+{
+    if(!c || level < 0 || level > 2) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    prof_collect(c);
+    c->profLevel = level;
+    return PRT_OK;
+}
+
+int prt_get_profile(prt_context* c, prt_profile* out)
+{
+    if(!c || !out) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    prof_collect(c);
+    unsigned long long st[kStatWords];
+    HIPCHK(c, hipMemcpyAsync(st, c->stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for(int k = 0; k < PRT_K_COUNT; ++k)
+    {
+        out->ms[k]       = c->profMs[k];
+        out->launches[k] = c->profLaunches[k];
+    }
+    out->closest_rays  = st[0];
+    out->any_rays      = st[1];
+    out->closest_nodes = st[2];
+    out->closest_tris  = st[3];
+    out->any_nodes     = st[4];
+    out->any_tris      = st[5];
     return PRT_OK;
 }
 

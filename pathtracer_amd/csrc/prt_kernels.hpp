@@ -51,7 +51,8 @@ struct FrameView
     float2*   aaOff;  // rayOffset (only read when numAArays != 1)
     uint32_t* hitIds; // primary-ray primitive id per pixel
     uint8_t*  dead;   // literal mode: pixel returned early in this iteration (primary miss)
-    unsigned long long* stats;  // [0] rays traced
+    unsigned long long* stats;  // [0] closest-hit rays, [1] any-hit rays, [2..3] nodes / triangles visited by
+                                // closest-hit rays, [4..5] by any-hit rays (profiling level 2 only)
 };
 
 PRT_DEV uint32_t wave_push(bool pred, uint32_t* counter)
@@ -76,10 +77,32 @@ PRT_DEV uint32_t wave_fetch(uint32_t* workCtr)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 }
 
-PRT_DEV void count_rays(const FrameView& f, bool active)
+// Per-lane tallies are kept in registers for the whole persistent loop and folded once per wave at the
+// end (all lanes have left the loop together, so the wave is converged for the shuffles).
+PRT_DEV uint32_t wave_sum(uint32_t v)
 {
-    const unsigned long long mask = __ballot(active);
-    if((threadIdx.x & 63) == 0 && mask) atomicAdd(f.stats, (unsigned long long)__popcll(mask));
+    for(int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+template <bool INSTR>
+PRT_DEV void flush_counts(const FrameView& f, uint32_t rays, TraceCount tc, int kind)
+{
+    const uint32_t r = wave_sum(rays);
+    uint32_t       n = 0, t = 0;
+    if(INSTR)
+    {
+        n = wave_sum(tc.nodes);
+        t = wave_sum(tc.tris);
+    }
+    if((threadIdx.x & 63) == 0)
+    {
+        if(r) atomicAdd(f.stats + kind, (unsigned long long)r);
+        if(INSTR)
+        {
+            atomicAdd(f.stats + 2 + 2 * kind, (unsigned long long)n);
+            atomicAdd(f.stats + 3 + 2 * kind, (unsigned long long)t);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -143,6 +166,7 @@ __global__ void __launch_bounds__(256) k_ao_generate(FrameView f, const prt_unif
 // ---------------------------------------------------------------------------------------------
 // extend — closest hit for every queued ray. queue == nullptr: identity (all pixels).
 // ---------------------------------------------------------------------------------------------
+template <bool INSTR>
 __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_extend(SceneView sc, FrameView f, const uint32_t* __restrict__ queue,
                                                             const uint32_t* __restrict__ countPtr,
                                                             uint32_t* workCtr, uint32_t primary)
@@ -150,24 +174,25 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_extend(SceneView sc, FrameV
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     const uint32_t      count = countPtr ? *countPtr : f.npix;
     const int           lane  = threadIdx.x & 63;
+    uint32_t            nrays = 0;
+    TraceCount          tc    = {0u, 0u};
     for(;;)
     {
         const uint32_t base = wave_fetch(workCtr);
         if(base >= count) break;
-        const uint32_t i      = base + lane;
-        bool           active = i < count;
-        if(active)
+        const uint32_t i = base + lane;
+        if(i < count)
         {
             const uint32_t px = queue ? queue[i] : i;
             const float4   o = f.rayO[px], d = f.rayD[px];
-            const Hit      h = trace_ray<false>(sc.bvh, &stackLds[threadIdx.x], mk3(o.x, o.y, o.z), o.w,
-                                                mk3(d.x, d.y, d.z), d.w);
+            const Hit      h = trace_ray<false, INSTR>(sc.bvh, &stackLds[threadIdx.x], mk3(o.x, o.y, o.z), o.w,
+                                                       mk3(d.x, d.y, d.z), d.w, &tc);
             f.hit[px] = make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t);
             if(primary) f.hitIds[px] = h.prim;
-            active = !(d.w < 0.0f);  // placeholder rays of pixels that already returned are not counted
+            if(!(d.w < 0.0f)) nrays++;  // placeholder rays of pixels that already returned are not counted
         }
-        count_rays(f, active);
     }
+    flush_counts<INSTR>(f, nrays, tc, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -453,6 +478,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const 
 // ---------------------------------------------------------------------------------------------
 // shadow + connect — traceNV(terminate on first hit) :818-822, then the accumulation of :939-942
 // ---------------------------------------------------------------------------------------------
+template <bool INSTR>
 __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_shadow(SceneView sc, FrameView f,
                                                             const uint32_t* __restrict__ queue,
                                                             const uint32_t* __restrict__ countPtr, uint32_t* workCtr)
@@ -460,24 +486,26 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_shadow(SceneView sc, FrameV
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     const uint32_t      count = *countPtr;
     const int           lane  = threadIdx.x & 63;
+    uint32_t            nrays = 0;
+    TraceCount          tc    = {0u, 0u};
     for(;;)
     {
         const uint32_t base = wave_fetch(workCtr);
         if(base >= count) break;
-        const uint32_t i      = base + lane;
-        const bool     active = i < count;
-        if(active)
+        const uint32_t i = base + lane;
+        if(i < count)
         {
             const uint32_t px = queue[i];
             const float4   o = f.shO[px], d = f.shD[px];
-            const Hit      h = trace_ray<true>(sc.bvh, &stackLds[threadIdx.x], mk3(o.x, o.y, o.z), 0.000001f,
-                                               mk3(d.x, d.y, d.z), 1.0f);
+            const Hit      h = trace_ray<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], mk3(o.x, o.y, o.z), 0.000001f,
+                                                      mk3(d.x, d.y, d.z), 1.0f, &tc);
             const float4   Ei = (h.prim != 0xffffffffu) ? f.eiOcc[px] : f.eiVis[px];
             const float4   E  = f.accum[px];
             f.accum[px]       = make_float4(E.x + Ei.x, E.y + Ei.y, E.z + Ei.z, E.w + o.w);
+            nrays++;
         }
-        count_rays(f, active);
     }
+    flush_counts<INSTR>(f, nrays, tc, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -493,6 +521,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
     const bool          literal = (flags & PRT_FLAG_LITERAL) != 0;
     const int           numAO   = ubo->numAOrays;
     const float         aoLen   = ubo->aoRayLength;
+    uint32_t            nrays   = 0;
     for(;;)
     {
         const uint32_t base = wave_fetch(workCtr);
@@ -552,12 +581,13 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
                     const Hit   h  = trace_ray<true>(sc.bvh, &stackLds[threadIdx.x], hitPoint, 0.00001f, Rd, 1.0f);
                     if(h.prim == 0xffffffffu) noHit++;
                 }
-                atomicAdd(f.stats, (unsigned long long)numAO);
+                nrays += (uint32_t)numAO;
                 const float ao = (float)noHit / (float)numAO;
                 f.accum[px]    = make_float4(E.x + ao, E.y + ao, E.z + ao, E.w + 1.0f);
             }
         }
     }
+    flush_counts<false>(f, nrays, TraceCount{0u, 0u}, 1);
 }
 
 // pathRTpostprocess.comp:38-51 over the whole image (the reference's W/16 x H/16 dispatch drops

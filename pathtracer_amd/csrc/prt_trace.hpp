@@ -188,8 +188,16 @@ struct LaneStack
 };
 
 // ANY = true: terminate-on-first-hit / skip-closest-hit-shader occlusion query (returns prim != ~0u on hit).
-template <bool ANY>
-PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* ldsStack, f3 o, float tmin, f3 d, float tmax)
+struct TraceCount
+{
+    uint32_t nodes, tris;
+};
+
+// INSTR = true additionally counts node visits and triangle tests (profiling level 2: the N_node / N_tri
+// of the algorithmic-bytes formula in DESIGN.md).
+template <bool ANY, bool INSTR = false>
+PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* ldsStack, f3 o, float tmin, f3 d, float tmax,
+                      TraceCount* tc = nullptr)
 {
     RayPre r;
     ray_prepare(bvh, o, d, r);
@@ -205,6 +213,7 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* ldsStack, f3 o, float tmin, 
         if(cur >= 0)
         {
             const float4* n  = bvh.nodes + (size_t)cur * 4;
+            if(INSTR) tc->nodes++;
             const float4  q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
             float         tl, tr;
             const bool    hl = slab_test(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, tmin, best.t, tl);
@@ -229,6 +238,7 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* ldsStack, f3 o, float tmin, 
             {
                 const float4 a = t[3 * i], b = t[3 * i + 1], c = t[3 * i + 2];
                 float        tt, uu, vv;
+                if(INSTR) tc->tris++;
                 if(tri_test(r, a, b, c, tmin, tmax, tt, uu, vv))
                 {
                     const uint32_t p = (uint32_t)__float_as_int(a.w);

@@ -234,8 +234,8 @@ def _normal_map_texture(rng, size):
     return np.ascontiguousarray(out)
 
 
-def conference_room(seed=2, detail=1.0, textured=False):
-    """BASELINE.json configs[1]: conference-room-scale closed interior, ~330k triangles at detail=1.
+def conference_room(seed=2, detail=1.4, textured=False):
+    """BASELINE.json configs[1]: conference-room-scale closed interior, ~330k triangles at the default detail=1.4.
 
     A 12 x 3.2 x 8 m closed room with tessellated walls, a long table, two rows of chairs with curved
     backs, ceiling fixtures, shelves with books, glass and glossy decoration. ``textured=True`` adds
