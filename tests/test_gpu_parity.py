@@ -1,0 +1,260 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (include/prt.h), against the CPU oracle on the
+same seeded inputs. Bar: bit-exact for primitive ids, BVH nodes / ordering and Sobol words; bit-exact for the
+fp32 accumulation buffer too, because oracle and kernels evaluate the same fp32 expression trees with
+contraction off and share the sin/cos polynomial (tolerance therefore 0 ulp; the north-star bar is only
+"rMSE under tolerance" for images). Full-size cases use size-independent properties."""
+import numpy as np
+import pytest
+
+from pathtracer_amd import capi, scenes, uniforms
+
+pytestmark = pytest.mark.gpu
+
+MISS = 0xFFFFFFFF
+
+
+def _pair(po, sc, W, H, seed=3, flags=0):
+    o = po.Oracle(sc, seed=seed)
+    o.build_bvh()
+    ctx = capi.Context(W, H)
+    ctx.set_scene(sc)
+    ctx.set_seed(seed)
+    ctx.build_accel()
+    ctx.set_flags(flags)
+    return o, ctx
+
+
+def _render_both(po, sc, W, H, mode, iters, flags=0, seed=3, **kw):
+    o, ctx = _pair(po, sc, W, H, seed, flags)
+    acc = np.zeros((H, W, 4), np.float32)
+    for it in iters:
+        u = uniforms.make_uniforms(sc, W, H, iteration=it, **kw)
+        acc, ids, rays = o.render(u, W, H, mode, accum=acc, flags=flags, want_ids=True)
+        ctx.set_uniforms(u)
+        ctx.reset_stats()
+        ctx.render_iteration(mode)
+        g = ctx.read_accum()
+        assert (ctx.read_hit_ids() == ids).all(), f"iteration {it}: primary hit ids differ"
+        assert ctx.stats().rays == rays, f"iteration {it}: ray count differs"
+        nd = int((g.view(np.uint32) != acc.view(np.uint32)).any(axis=-1).sum())
+        assert nd == 0, f"iteration {it}: {nd} pixels differ, max abs {np.nanmax(np.abs(g - acc))}"
+    ctx.close()
+
+
+def test_sobol_table_equals_reference_words(po):
+    ctx = capi.Context(8, 8)
+    assert (ctx.read_sobol() == po.golden_sobol()[:, :32]).all()
+    ctx.close()
+
+
+@pytest.mark.parametrize("maker", [scenes.cornell_box, lambda: scenes.random_soup(5000),
+                                   lambda: scenes.random_soup(3), lambda: scenes.conference_room(detail=0.5)])
+def test_gpu_bvh_is_the_oracle_bvh(po, maker):
+    sc = maker()
+    o, ctx = _pair(po, sc, 16, 16)
+    gn, go = ctx.read_bvh()
+    on, oo = o.bvh()
+    assert len(gn) == len(on) and ctx.stats().bvh_depth == o.bvh_depth()
+    assert gn.tobytes() == on.tobytes()
+    assert (go == oo).all()
+    ctx.close()
+
+
+def test_gpu_bvh_degenerate_centroids(po):
+    mb = scenes.MeshBuilder()
+    tri = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32)
+    mb.add(np.repeat(tri, 37, 0), 0)
+    mb.add(tri + 2.0, 0)
+    sc = mb.finish([scenes.make_material()])
+    o, ctx = _pair(po, sc, 16, 16)
+    gn, go = ctx.read_bvh()
+    on, oo = o.bvh()
+    assert gn.tobytes() == on.tobytes() and (go == oo).all()
+    ctx.close()
+
+
+def _rays(n, seed, extent):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, capi.RAY_DTYPE)
+    rays["o"] = rng.uniform(-extent, extent, (n, 3))
+    d = rng.uniform(-extent * 0.7, extent * 0.7, (n, 3)) - rays["o"]
+    rays["d"] = d * rng.uniform(0.3, 3.0, (n, 1))
+    rays["tmin"], rays["tmax"] = 1e-6, 1.0
+    return rays
+
+
+@pytest.mark.parametrize("maker,extent", [(lambda: scenes.random_soup(5000), 6.0), (scenes.cornell_box, 3.0),
+                                          (lambda: scenes.conference_room(detail=0.4), 5.0),
+                                          (lambda: scenes.random_soup(2), 3.0)])
+def test_trace_matches_oracle_and_brute_force(po, maker, extent):
+    sc = maker()
+    o, ctx = _pair(po, sc, 16, 16)
+    rays = _rays(20000, 11, extent)
+    g = ctx.trace(rays)
+    c = o.trace_closest(rays)
+    assert g.tobytes() == c.tobytes()  # prim, u, v, t all bit-exact
+    b = o.trace_closest(rays[:4000], brute=True)
+    assert g[:4000].tobytes() == b.tobytes()  # and independent of the BVH
+    ga = ctx.trace(rays, any_hit=True)
+    assert ((ga["prim"] != MISS) == (o.trace_any(rays) == 1)).all()
+    ctx.close()
+
+
+def test_trace_edge_cases(po):
+    sc = scenes.cornell_box()
+    o, ctx = _pair(po, sc, 16, 16)
+    assert len(ctx.trace(np.zeros(0, capi.RAY_DTYPE))) == 0  # empty batch
+    rays = np.zeros(6, capi.RAY_DTYPE)
+    rays["o"] = (0.1, 1.0, 0.3)
+    rays["d"] = [(1, 0, 0), (0, 1, 0), (0, 0, -1), (0, -3, 0), (0, 0, 0), (1e-30, 5, 1e-30)]  # axis aligned, zero
+    rays["tmin"] = [1e-6, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6]
+    rays["tmax"] = [10, 10, 10, 0.1, 1, 1]
+    g, c = ctx.trace(rays), o.trace_closest(rays)
+    assert g.tobytes() == c.tobytes()
+    assert g["prim"][3] == MISS and g["prim"][4] == MISS
+    ctx.close()
+
+
+def test_config0_cornell_ao_512(po):
+    """BASELINE.json configs[0]: Cornell box 512x512, AO mode, 16 rays."""
+    _render_both(po, scenes.cornell_box(), 512, 512, capi.MODE_AO, [1], seed=1, ao_rays=16, ao_length=1.0)
+
+
+@pytest.mark.parametrize("case", ["cornell", "cornell_literal", "soup_open", "soup_aa4", "soup_aa3_literal", "rr",
+                                  "conference", "conference_textured", "bounce0", "ao_multi"])
+def test_path_and_ao_bit_exact(po, case):
+    if case == "cornell":
+        _render_both(po, scenes.cornell_box(), 160, 128, 0, [1, 2, 3], bounces=5, light_area=0.2)
+    elif case == "cornell_literal":
+        _render_both(po, scenes.cornell_box(), 128, 128, 0, [1, 2, 1, 5], flags=capi.FLAG_LITERAL, bounces=3)
+    elif case == "soup_open":
+        _render_both(po, scenes.random_soup(4000), 160, 120, 0, [1, 2], bounces=4)
+    elif case == "soup_aa4":
+        _render_both(po, scenes.random_soup(2000), 96, 64, 0, [1, 5], bounces=2, aa_rays=4)
+    elif case == "soup_aa3_literal":
+        _render_both(po, scenes.random_soup(2000), 96, 64, 0, [1, 4], flags=capi.FLAG_LITERAL, bounces=2, aa_rays=3)
+    elif case == "rr":
+        _render_both(po, scenes.cornell_box(), 128, 96, 0, [1, 2, 3], flags=capi.FLAG_RUSSIAN_ROULETTE, bounces=8,
+                     light_area=0.3)
+    elif case == "conference":
+        _render_both(po, scenes.conference_room(detail=0.5), 320, 180, 0, [1, 2], bounces=5)
+    elif case == "conference_textured":
+        _render_both(po, scenes.conference_room(detail=0.4, textured=True), 320, 180, 0, [1, 2], bounces=5)
+    elif case == "bounce0":
+        _render_both(po, scenes.cornell_box(), 64, 64, 0, [1], bounces=0)
+    elif case == "ao_multi":
+        _render_both(po, scenes.random_soup(3000), 128, 96, 1, [0, 2, 3], ao_rays=7, ao_length=2.5)
+
+
+def test_uploaded_scramble_table(po):
+    """The reference's explicit 32-layer scramble image (vkRTX_setup.cpp:808-911) instead of the hash."""
+    sc = scenes.cornell_box()
+    W, H = 64, 48
+    table = np.random.default_rng(123).integers(0, 2 ** 32, (32, H * W), dtype=np.uint64).astype(np.uint32)
+    o, ctx = _pair(po, sc, W, H)
+    o.set_scramble_table(table, W, H)
+    ctx.upload_scrambles(table)
+    u = uniforms.make_uniforms(sc, W, H, bounces=3, iteration=1)
+    ctx.set_uniforms(u)
+    ctx.render_iteration(0)
+    acc, _, _ = o.render(u, W, H, 0)
+    assert ctx.read_accum().tobytes() == acc.tobytes()
+    ctx.close()
+
+
+def test_api_errors():
+    ctx = capi.Context(32, 32)
+    with pytest.raises(capi.PrtError):
+        ctx.render_iteration(0)  # no scene
+    with pytest.raises(capi.PrtError):
+        ctx.build_accel()
+    sc = scenes.cornell_box()
+    bad = dict(sc)
+    bad["indices"] = sc["indices"].copy()
+    bad["indices"][5] = 10 ** 6
+    with pytest.raises(capi.PrtError):
+        ctx.set_scene(bad)
+    ctx.set_scene(sc)
+    ctx.build_accel()
+    with pytest.raises(capi.PrtError):
+        ctx.render_iteration(7)
+    u = uniforms.make_uniforms(sc, 32, 32, bounces=99)
+    with pytest.raises(capi.PrtError):
+        ctx.set_uniforms(u)
+    # ragged index count: trailing indices that do not form a triangle are ignored
+    rag = dict(sc)
+    rag["indices"] = np.concatenate([sc["indices"], sc["indices"][:2]])
+    ctx.set_scene(rag)
+    ctx.build_accel()
+    assert ctx.stats().bvh_nodes > 0
+    ctx.close()
+
+
+def test_postprocess_matches_oracle(po):
+    sc = scenes.cornell_box()
+    W = H = 64
+    o, ctx = _pair(po, sc, W, H)
+    u = uniforms.make_uniforms(sc, W, H, ao_rays=8)
+    ctx.set_uniforms(u)
+    ctx.render_iteration(1)
+    img = ctx.postprocess()
+    ref = po.postprocess(ctx.read_accum(), W, H)
+    assert np.abs(img.astype(np.int32) - ref.astype(np.int32)).max() <= 1  # powf vs __powf: +-1 code value
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[1] at full size: properties that do not need a full oracle render
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def conference_full():
+    sc = scenes.conference_room(seed=2, detail=1.4)
+    ctx = capi.Context(1920, 1080)
+    ctx.set_scene(sc)
+    ctx.set_seed(2)
+    ctx.build_accel()
+    yield sc, ctx
+    ctx.close()
+
+
+def test_full_size_primary_hit_ids_bit_exact(po, conference_full):
+    sc, ctx = conference_full
+    W, H = 1920, 1080
+    u = uniforms.make_uniforms(sc, W, H, bounces=0, iteration=1)
+    ctx.clear_accum()
+    ctx.set_uniforms(u)
+    ctx.render_iteration(0)
+    gid = ctx.read_hit_ids()
+    o = po.Oracle(sc, seed=2)
+    _, ids, _ = o.render(u, W, H, 0, want_ids=True)
+    assert (gid == ids).all()
+    assert (gid != MISS).all()  # closed room
+
+
+def test_full_size_properties(conference_full):
+    sc, ctx = conference_full
+    W, H, B = 1920, 1080, 5
+
+    def run(iters):
+        ctx.clear_accum()
+        ctx.reset_stats()
+        for it in iters:
+            ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=B, iteration=it))
+            ctx.render_iteration(0)
+        return ctx.read_accum(), ctx.stats().rays
+
+    a, rays = run([1, 2, 3, 4])
+    b, rays_b = run([1, 2, 3, 4])
+    assert a.tobytes() == b.tobytes() and rays == rays_b  # deterministic
+    assert np.isfinite(a).all() and (a[..., :3] >= 0).all()
+    w = a[..., 3]
+    assert (w == np.round(w)).all() and w.min() >= 4 and w.max() <= 4 * (B + 1)  # vertices per path in [1, B+1]
+    assert W * H * 4 * 2 <= rays <= W * H * 4 * (2 * B + 2)  # <= 2B+2 rays per sample
+    # sample sharding (multi-GPU rule): shards sum to the whole within fp32 reassociation
+    s0, r0 = run([1, 3])
+    s1, r1 = run([2, 4])
+    assert r0 + r1 == rays
+    assert (s0[..., 3] + s1[..., 3] == w).all()
+    num = ((s0 + s1 - a)[..., :3] ** 2).mean()
+    den = (a[..., :3] ** 2).mean()
+    assert num / den < 1e-10
