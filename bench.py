@@ -140,9 +140,10 @@ def main():
         ct = prof2.closest_tris / max(1, prof2.closest_rays)
         an = prof2.any_nodes / max(1, prof2.any_rays)
         at = prof2.any_tris / max(1, prof2.any_rays)
-        # B_ray = 32 + 32 (ray record w+r) + 16 + 16 (hit w+r) + N_node*64 + N_tri*48
-        b_closest = 96.0 + cn * 64.0 + ct * 48.0
-        b_any = 96.0 + an * 64.0 + at * 48.0
+        # B_ray = 32 + 32 (ray record w+r) + 16 + 16 (hit w+r) + N_node*S_node + N_tri*48,
+        # S_node = 128 (BVH4 node = one 128-byte line)
+        b_closest = 96.0 + cn * 128.0 + ct * 48.0
+        b_any = 96.0 + an * 128.0 + at * 48.0
         if p.ms[capi.K_EXTEND] >= p.ms[capi.K_SHADOW]:
             kind, kname, b_ray, nrays = capi.K_EXTEND, "k_extend (closest-hit traversal)", b_closest, p.closest_rays
             nn, nt = cn, ct

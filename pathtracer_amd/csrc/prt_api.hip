@@ -41,7 +41,7 @@ struct prt_context
     // acceleration structure
     BuildNode* dBuildNodes = nullptr;
     uint32_t*  dOrder      = nullptr;
-    Node64*    dNodes      = nullptr;
+    float4*    dNodes      = nullptr;  // BVH4, 8 x float4 per node
     float4*    dTris       = nullptr;
     uint32_t   nNodes = 0, nInner = 0, depth = 0;
     int32_t    root     = 0;
@@ -122,6 +122,26 @@ static void dfree(T*& p)
 static inline uint32_t cdiv(size_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
 static void prof_collect(prt_context* c);
+
+// traversal knobs; PRT_TUNE="refillMin,stallMax,leafMin" overrides (measurement only)
+static TraceTune trace_tune()
+{
+    static TraceTune t = [] {
+        TraceTune v{24u, 16u, 24u, 0u};
+        if(const char* e = getenv("PRT_TUNE"))
+        {
+            unsigned a = v.refillMin, b = v.stallMax, d = v.leafMin;
+            if(sscanf(e, "%u,%u,%u", &a, &b, &d) >= 1)
+            {
+                v.refillMin = a < 1 ? 1 : (a > 64 ? 64 : a);
+                v.stallMax  = b > 64 ? 64 : b;
+                v.leafMin   = d < 1 ? 1 : (d > 64 ? 64 : d);
+            }
+        }
+        return v;
+    }();
+    return t;
+}
 
 static void free_scene(prt_context* c)
 {
@@ -354,9 +374,12 @@ int prt_build_accel(prt_context* c)
     hipLaunchKernelGGL(k_build_reset, dim3(1), dim3(64), 0, st, c->dBuildNodes, cb, N);
     hipLaunchKernelGGL(k_prim_boxes, dim3(cdiv(N, 256)), dim3(256), 0, st, c->dVerts, c->dIdx, N, pbox, orderCur,
                        nodeOf, c->dBuildNodes, cb);
-    uint32_t levelStart = 0, levelCount = 1, nNodes = 1, depth = 1;
+    uint32_t   levelStart = 0, levelCount = 1, nNodes = 1, depth = 1;
+    LevelTable lt;
+    memset(&lt, 0, sizeof lt);
     for(;;)
     {
+        lt.start[lt.n++] = levelStart;
         hipLaunchKernelGGL(k_level_flags, dim3(cdiv(levelCount, 256)), dim3(256), 0, st, c->dBuildNodes, levelStart,
                            levelCount, rank);
         rc = device_scan(c, rank, levelCount, tileSums, total);
@@ -397,16 +420,17 @@ int prt_build_accel(prt_context* c)
     if(orderCur != c->dOrder)
         BCHK(hipMemcpyAsync(c->dOrder, orderCur, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
 
-    // traversal layout
-    hipLaunchKernelGGL(k_inner_flags, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, flags);
+    // traversal layout: BVH4 (see prt_bvh.hpp)
+    hipLaunchKernelGGL(k_wide_flags, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, lt, flags);
     rc = device_scan(c, flags, nNodes, tileSums, total);
     if(rc) { cleanup(); return rc; }
     uint32_t nInner = 0;
     BCHK(hipMemcpyAsync(&nInner, total, 4, hipMemcpyDeviceToHost, st));
     BCHK(hipStreamSynchronize(st));
-    BCHK(dalloc(c->dNodes, (size_t)(nInner ? nInner : 1)));
+    if(nInner >= (1u << 25)) { cleanup(); return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^25 BVH4 nodes"); }
+    BCHK(dalloc(c->dNodes, (size_t)(nInner ? nInner : 1) * 8));
     BCHK(dalloc(c->dTris, (size_t)3 * N));
-    hipLaunchKernelGGL(k_emit_nodes, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, flags,
+    hipLaunchKernelGGL(k_emit_wide, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, lt, flags,
                        c->dNodes);
     hipLaunchKernelGGL(k_emit_tris, dim3(cdiv(N, 256)), dim3(256), 0, st, c->dVerts, c->dIdx, c->dOrder, N, c->dTris);
     BCHK(hipGetLastError());
@@ -545,7 +569,7 @@ static void make_views(prt_context* c, SceneView& sc, FrameView& f)
     sc.ntex         = c->ntex;
     sc.seed         = c->seed;
     sc.ntri         = c->ntri;
-    sc.bvh.nodes    = (const float4*)c->dNodes;
+    sc.bvh.nodes    = c->dNodes;
     sc.bvh.tris     = c->dTris;
     sc.bvh.root     = c->root;
     sc.bvh.sceneAbs = c->sceneAbs;
@@ -572,10 +596,11 @@ static void launch_extend(prt_context* c, const SceneView& sc, const FrameView& 
 {
     ProfScope ps(c, PRT_K_EXTEND);
     if(c->profLevel >= 2)
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc, f, q, n, work, primary);
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc, f, q, n, work, primary,
+                           trace_tune());
     else
         hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc, f, q, n, work,
-                           primary);
+                           primary, trace_tune());
 }
 
 // One vkCmdTraceRaysNV(W,H,1): a fixed launch sequence, no host synchronisation.
@@ -645,11 +670,11 @@ static int render_one(prt_context* c, int mode)
                 if(c->profLevel >= 2)
                     hipLaunchKernelGGL(k_shadow<true>, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
                                        (const uint32_t*)c->qShadow, (const uint32_t*)(c->counters + 32 + b),
-                                       c->counters + 128 + b);
+                                       c->counters + 128 + b, trace_tune());
                 else
                     hipLaunchKernelGGL(k_shadow<false>, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
                                        (const uint32_t*)c->qShadow, (const uint32_t*)(c->counters + 32 + b),
-                                       c->counters + 128 + b);
+                                       c->counters + 128 + b, trace_tune());
             }
             if(c->pending.size() > 8192) prof_collect(c);
         }
@@ -822,13 +847,17 @@ int prt_trace_device(prt_context* c, const void* rays, size_t n, int any, void* 
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
+    // counters[192]: work-fetch cursor of this launch (the render passes use words 0..191)
+    uint32_t*      work = c->counters + 192;
+    const uint32_t grid = (uint32_t)c->numCU * 6u;
+    HIPCHK(c, hipMemsetAsync(work, 0, 4, c->stream));
     HIPCHK(c, hipEventRecord(e0, c->stream));
     if(any)
-        hipLaunchKernelGGL(k_trace_batch<true>, dim3(cdiv(n, PRT_TRACE_BLOCK)), dim3(PRT_TRACE_BLOCK), 0, c->stream,
-                           sc.bvh, (const float4*)rays, (uint32_t)n, (float4*)hits);
+        hipLaunchKernelGGL(k_trace_batch<true>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc.bvh,
+                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune());
     else
-        hipLaunchKernelGGL(k_trace_batch<false>, dim3(cdiv(n, PRT_TRACE_BLOCK)), dim3(PRT_TRACE_BLOCK), 0, c->stream,
-                           sc.bvh, (const float4*)rays, (uint32_t)n, (float4*)hits);
+        hipLaunchKernelGGL(k_trace_batch<false>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc.bvh,
+                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune());
     hipError_t e = hipGetLastError();
     if(e == hipSuccess) e = hipEventRecord(e1, c->stream);
     if(e == hipSuccess) e = hipEventSynchronize(e1);

@@ -490,36 +490,78 @@ __global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ or
     }
 }
 
-// ---- emit the traversal layout -----------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_inner_flags(const BuildNode* __restrict__ nodes, uint32_t nnodes,
-                                                     uint32_t* __restrict__ flags)
+// ---- emit the traversal layout: collapse the binary build tree into BVH4 ------------------------------
+// A wide node is made from every inner build node on an EVEN level: its slots are its grandchildren
+// (children that are leaves stay as they are), in left-to-right order. Child reference: >= 0 index of a
+// wide node, < 0 ~((first << 3) | count) for a leaf over tris[first .. first+count); empty slots carry an
+// inverted box (min = +inf, max = -inf) that no ray enters.
+struct LevelTable
+{
+    uint32_t start[PRT_MAX_DEPTH + 2];  // first build-node index of every level (levels are contiguous)
+    uint32_t n;
+};
+PRT_DEV uint32_t level_of(const LevelTable& lt, uint32_t i)
+{
+    uint32_t l = 0;
+    while(l + 1 < lt.n && i >= lt.start[l + 1]) ++l;
+    return l;
+}
+__global__ void __launch_bounds__(256) k_wide_flags(const BuildNode* __restrict__ nodes, uint32_t nnodes,
+                                                    LevelTable lt, uint32_t* __restrict__ flags)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if(i < nnodes) flags[i] = nodes[i].count == 0 ? 1u : 0u;
+    if(i < nnodes) flags[i] = (nodes[i].count == 0 && (level_of(lt, i) & 1u) == 0u) ? 1u : 0u;
 }
-PRT_DEV int32_t child_ref(const BuildNode& c, uint32_t ci, const uint32_t* innerIdx)
-{
-    return c.count == 0 ? (int32_t)innerIdx[ci] : (int32_t)~((c.first << 3) | c.count);
-}
-__global__ void __launch_bounds__(256) k_emit_nodes(const BuildNode* __restrict__ nodes, uint32_t nnodes,
-                                                    const uint32_t* __restrict__ innerIdx, Node64* __restrict__ out)
+__global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__ nodes, uint32_t nnodes,
+                                                   LevelTable lt, const uint32_t* __restrict__ wideIdx,
+                                                   float4* __restrict__ out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if(i >= nnodes || nodes[i].count != 0) return;
-    const uint32_t  li = nodes[i].first, ri = li + 1;
-    const BuildNode l = nodes[li], r = nodes[ri];
-    Node64          n;
+    if(i >= nnodes || nodes[i].count != 0 || (level_of(lt, i) & 1u) != 0u) return;
+    uint32_t slot[4];
+    int      n = 0;
+    for(uint32_t c = nodes[i].first; c < nodes[i].first + 2; ++c)
+    {
+        if(nodes[c].count == 0)
+        {
+            slot[n++] = nodes[c].first;
+            slot[n++] = nodes[c].first + 1;
+        }
+        else
+            slot[n++] = c;
+    }
+    float   mn[3][4], mx[3][4];
+    int32_t ref[4];
+    for(int j = 0; j < 4; ++j)
+    {
+        if(j < n)
+        {
+            const BuildNode c = nodes[slot[j]];
+            for(int k = 0; k < 3; ++k)
+            {
+                mn[k][j] = fdec(c.bmin[k]);
+                mx[k][j] = fdec(c.bmax[k]);
+            }
+            ref[j] = c.count == 0 ? (int32_t)wideIdx[slot[j]] : (int32_t)~((c.first << 3) | c.count);
+        }
+        else
+        {
+            for(int k = 0; k < 3; ++k)
+            {
+                mn[k][j] = __builtin_inff();
+                mx[k][j] = -__builtin_inff();
+            }
+            ref[j] = -1;
+        }
+    }
+    float4* o = out + (size_t)wideIdx[i] * 8;
     for(int k = 0; k < 3; ++k)
     {
-        n.lmin[k] = fdec(l.bmin[k]);
-        n.lmax[k] = fdec(l.bmax[k]);
-        n.rmin[k] = fdec(r.bmin[k]);
-        n.rmax[k] = fdec(r.bmax[k]);
+        o[2 * k]     = make_float4(mn[k][0], mn[k][1], mn[k][2], mn[k][3]);
+        o[2 * k + 1] = make_float4(mx[k][0], mx[k][1], mx[k][2], mx[k][3]);
     }
-    n.left  = child_ref(l, li, innerIdx);
-    n.right = child_ref(r, ri, innerIdx);
-    n.pad0 = n.pad1 = 0;
-    out[innerIdx[i]] = n;
+    o[6] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(ref[2]), __int_as_float(ref[3]));
+    o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 __global__ void __launch_bounds__(256) k_emit_tris(const prt_vertex* __restrict__ verts,
                                                    const uint32_t* __restrict__ idx,

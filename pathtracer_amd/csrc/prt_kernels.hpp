@@ -166,32 +166,40 @@ __global__ void __launch_bounds__(256) k_ao_generate(FrameView f, const prt_unif
 // ---------------------------------------------------------------------------------------------
 // extend — closest hit for every queued ray. queue == nullptr: identity (all pixels).
 // ---------------------------------------------------------------------------------------------
+struct ExtendIO
+{
+    const FrameView& f;
+    const uint32_t*  queue;
+    uint32_t         primary;
+    PRT_DEV bool load(uint32_t i, f3& o, float& tmin, f3& d, float& tmax, uint32_t& tag) const
+    {
+        const uint32_t px = queue ? queue[i] : i;
+        const float4   oq = f.rayO[px], dq = f.rayD[px];
+        o    = mk3(oq.x, oq.y, oq.z);
+        tmin = oq.w;
+        d    = mk3(dq.x, dq.y, dq.z);
+        tmax = dq.w;
+        tag  = px;
+        return !(dq.w < 0.0f);  // placeholder rays of pixels that already returned are not counted
+    }
+    PRT_DEV void store(uint32_t px, const Hit& h) const
+    {
+        f.hit[px] = make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t);
+        if(primary) f.hitIds[px] = h.prim;
+    }
+};
+
 template <bool INSTR>
 __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_extend(SceneView sc, FrameView f, const uint32_t* __restrict__ queue,
                                                             const uint32_t* __restrict__ countPtr,
-                                                            uint32_t* workCtr, uint32_t primary)
+                                                            uint32_t* workCtr, uint32_t primary, TraceTune tune)
 {
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     const uint32_t      count = countPtr ? *countPtr : f.npix;
-    const int           lane  = threadIdx.x & 63;
     uint32_t            nrays = 0;
     TraceCount          tc    = {0u, 0u};
-    for(;;)
-    {
-        const uint32_t base = wave_fetch(workCtr);
-        if(base >= count) break;
-        const uint32_t i = base + lane;
-        if(i < count)
-        {
-            const uint32_t px = queue ? queue[i] : i;
-            const float4   o = f.rayO[px], d = f.rayD[px];
-            const Hit      h = trace_ray<false, INSTR>(sc.bvh, &stackLds[threadIdx.x], mk3(o.x, o.y, o.z), o.w,
-                                                       mk3(d.x, d.y, d.z), d.w, &tc);
-            f.hit[px] = make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t);
-            if(primary) f.hitIds[px] = h.prim;
-            if(!(d.w < 0.0f)) nrays++;  // placeholder rays of pixels that already returned are not counted
-        }
-    }
+    ExtendIO            io{f, queue, primary};
+    trace_stream<false, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nrays, tc);
     flush_counts<INSTR>(f, nrays, tc, 0);
 }
 
@@ -478,33 +486,41 @@ __global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const 
 // ---------------------------------------------------------------------------------------------
 // shadow + connect — traceNV(terminate on first hit) :818-822, then the accumulation of :939-942
 // ---------------------------------------------------------------------------------------------
+struct ShadowIO
+{
+    const FrameView& f;
+    const uint32_t*  queue;
+    PRT_DEV bool load(uint32_t i, f3& o, float& tmin, f3& d, float& tmax, uint32_t& tag) const
+    {
+        const uint32_t px = queue[i];
+        const float4   oq = f.shO[px], dq = f.shD[px];
+        o    = mk3(oq.x, oq.y, oq.z);
+        tmin = 0.000001f;
+        d    = mk3(dq.x, dq.y, dq.z);
+        tmax = 1.0f;
+        tag  = px;
+        return true;
+    }
+    PRT_DEV void store(uint32_t px, const Hit& h) const
+    {
+        const float4 Ei = (h.prim != 0xffffffffu) ? f.eiOcc[px] : f.eiVis[px];
+        const float4 E  = f.accum[px];
+        f.accum[px]     = make_float4(E.x + Ei.x, E.y + Ei.y, E.z + Ei.z, E.w + f.shO[px].w);
+    }
+};
+
 template <bool INSTR>
 __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_shadow(SceneView sc, FrameView f,
                                                             const uint32_t* __restrict__ queue,
-                                                            const uint32_t* __restrict__ countPtr, uint32_t* workCtr)
+                                                            const uint32_t* __restrict__ countPtr, uint32_t* workCtr,
+                                                            TraceTune tune)
 {
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     const uint32_t      count = *countPtr;
-    const int           lane  = threadIdx.x & 63;
     uint32_t            nrays = 0;
     TraceCount          tc    = {0u, 0u};
-    for(;;)
-    {
-        const uint32_t base = wave_fetch(workCtr);
-        if(base >= count) break;
-        const uint32_t i = base + lane;
-        if(i < count)
-        {
-            const uint32_t px = queue[i];
-            const float4   o = f.shO[px], d = f.shD[px];
-            const Hit      h = trace_ray<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], mk3(o.x, o.y, o.z), 0.000001f,
-                                                      mk3(d.x, d.y, d.z), 1.0f, &tc);
-            const float4   Ei = (h.prim != 0xffffffffu) ? f.eiOcc[px] : f.eiVis[px];
-            const float4   E  = f.accum[px];
-            f.accum[px]       = make_float4(E.x + Ei.x, E.y + Ei.y, E.z + Ei.z, E.w + o.w);
-            nrays++;
-        }
-    }
+    ShadowIO            io{f, queue};
+    trace_stream<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nrays, tc);
     flush_counts<INSTR>(f, nrays, tc, 1);
 }
 
@@ -619,17 +635,36 @@ __global__ void __launch_bounds__(256) k_postprocess(const float4* __restrict__ 
     rgba8[i] = out;
 }
 
-// generic batch trace for prt_trace() (unit tests / ray-level benchmarks)
+// generic batch trace for prt_trace() (unit tests / ray-level benchmarks): same persistent stream
+struct BatchIO
+{
+    const float4* rays;
+    float4*       hits;
+    PRT_DEV bool load(uint32_t i, f3& o, float& tmin, f3& d, float& tmax, uint32_t& tag) const
+    {
+        const float4 oq = rays[2 * (size_t)i], dq = rays[2 * (size_t)i + 1];
+        o    = mk3(oq.x, oq.y, oq.z);
+        tmin = oq.w;
+        d    = mk3(dq.x, dq.y, dq.z);
+        tmax = dq.w;
+        tag  = i;
+        return true;
+    }
+    PRT_DEV void store(uint32_t i, const Hit& h) const
+    {
+        hits[i] = make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t);
+    }
+};
 template <bool ANY>
 __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_trace_batch(BvhView bvh, const float4* __restrict__ rays,
-                                                                 uint32_t n, float4* __restrict__ hits)
+                                                                 uint32_t n, float4* __restrict__ hits,
+                                                                 uint32_t* workCtr, TraceTune tune)
 {
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
-    const uint32_t      i = blockIdx.x * blockDim.x + threadIdx.x;
-    if(i >= n) return;
-    const float4 o = rays[2 * i], d = rays[2 * i + 1];
-    const Hit    h = trace_ray<ANY>(bvh, &stackLds[threadIdx.x], mk3(o.x, o.y, o.z), o.w, mk3(d.x, d.y, d.z), d.w);
-    hits[i]        = make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t);
+    uint32_t            nrays = 0;
+    TraceCount          tc    = {0u, 0u};
+    BatchIO             io{rays, hits};
+    trace_stream<ANY, false>(bvh, &stackLds[threadIdx.x], n, workCtr, tune, io, nrays, tc);
 }
 
 }  // namespace prt

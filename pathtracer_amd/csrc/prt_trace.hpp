@@ -1,45 +1,48 @@
 // prt_trace.hpp — wave64 BVH traversal for gfx950: replaces traceNV / the RT cores
 // (shaders/pathRT.rgen:692,819-822,963; shaders/AO.rgen:215,259-262).
 //
-// * BVH2, 64-byte nodes that hold BOTH child boxes: one node visit = four 16-byte loads from one
-//   64-byte line (half of a 128-byte HBM/L2 line, so sibling-order BFS layout pairs them).
+// * BVH4, 128-byte nodes (one HBM/L2 line): six rows of four floats (min x, max x, min y, max y, min z,
+//   max z of the four children) + one row of four child references. A ray picks the near / far row of
+//   each axis BY ADDRESS (row offset ^ 16 from the sign of its direction), so the slab test has no
+//   per-child selects: one fma per plane, v_max3/v_min3 for the interval.
 // * Leaves reference runs of <= 4 pre-gathered triangles, 48 bytes each (3 x float4, prim id in
 //   v0.w), laid out in leaf order so a leaf is one contiguous 48..192-byte read.
-// * Per-lane traversal stack: the first PRT_LDS_STACK entries live in LDS, laid out
-//   [entry][lane] so that a wave's push/pop is one conflict-free ds_write_b32/ds_read_b32;
-//   deeper entries (rare: the SAH trees built here are 20-35 levels deep) spill to scratch.
+// * Per-lane traversal stack: the first PRT_LDS_STACK entries live in LDS, laid out [entry][lane] so
+//   that a wave's push/pop is one conflict-free ds_write_b32/ds_read_b32; deeper entries (rare)
+//   spill to scratch.
+// * trace_stream(): persistent waves. A wave keeps up to 64 rays in flight; lanes whose ray has
+//   finished are refilled from the queue (chunked work fetch, one atomic per PRT_CHUNK rays), node
+//   steps and triangle tests run in separate wave-uniform phases (a found leaf is postponed while the
+//   lane keeps descending), so that divergence between "at a node" and "at a leaf" lanes and between
+//   short and long rays does not idle the SIMD.
 // * Watertight ray/triangle test (Woop, Benthin, Wald 2013) with the fp64 fallback for edge
 //   functions that evaluate to exactly 0; two-sided triangles (TRIANGLE_CULL_DISABLE,
 //   vkRT_TLAS.cpp:218-223); hit iff tmin < t < tmax; closest hit ties -> lower primitive id.
-// * Conservative slab test: boxes grown by 64*2^-24*max(|origin|, |scene|), distances widened by 4 ulp.
+//   The result of a trace is therefore independent of the tree and of the traversal order; the box
+//   test only has to be conservative: boxes grown by 64*2^-24*max(|origin|, |scene|), slab distances
+//   widened by 2^-21 (covers v_rcp_f32 + the fma rounding).
 #pragma once
 #include "prt_device.hpp"
 
 namespace prt {
 
 #define PRT_LDS_STACK 24
-#define PRT_SPILL_STACK 40
-#define PRT_MAX_DEPTH (PRT_LDS_STACK + PRT_SPILL_STACK)
+#define PRT_SPILL_STACK 80
+#define PRT_MAX_DEPTH 64  // depth limit of the binary build tree (=> <= 33 BVH4 levels, <= 100 stack entries)
 #define PRT_TRACE_BLOCK 256
+#define PRT_NODE_BYTES 128
+#define PRT_CHUNK 128u
 
-struct alignas(16) Node64
-{
-    float   lmin[3];
-    int32_t left;  // >= 0: inner node index; < 0: ~((first << 3) | count)
-    float   lmax[3];
-    int32_t right;
-    float   rmin[3];
-    uint32_t pad0;
-    float   rmax[3];
-    uint32_t pad1;
-};
-static_assert(sizeof(Node64) == 64, "node is one 64-byte line");
+static_assert(1 + 3 * (PRT_MAX_DEPTH / 2 + 1) <= PRT_LDS_STACK + PRT_SPILL_STACK, "stack covers the deepest tree");
+
+constexpr int32_t kSentinel  = 0x7fffffff;  // bottom-of-stack marker: the ray is finished
+constexpr int32_t kEmptyLeaf = -1;          // ~0: leaf reference with count 0
 
 struct BvhView
 {
-    const float4* nodes;  // Node64 as 4 x float4
+    const float4* nodes;  // 8 x float4 per BVH4 node
     const float4* tris;   // 3 x float4 per triangle, leaf order
-    int32_t       root;   // node index, or a leaf reference when the scene has <= 4 triangles
+    int32_t       root;   // node index (0), or a leaf reference when the scene has <= 4 triangles
     float         sceneAbs;
 };
 
@@ -49,29 +52,46 @@ struct Hit
     float    u, v, t;
 };
 
-struct RayPre
+struct TraceCount
 {
-    float ox, oy, oz;
-    float Sx, Sy, Sz;
-    int   kx, ky, kz;
-    float onx, ony, onz, ofx, ofy, ofz;  // padded origins for near / far planes
-    float rnx, rny, rnz, rfx, rfy, rfz;  // widened reciprocal directions
-    bool  negx, negy, negz;
+    uint32_t nodes, tris;
+};
+
+// traversal knobs (wave-uniform kernel argument)
+struct TraceTune
+{
+    uint32_t refillMin;  // refill when at least this many lanes are idle
+    uint32_t stallMax;   // leave the node phase when more than this many active lanes wait at a leaf / are done
+    uint32_t leafMin;    // run another triangle round only when at least this many lanes have a leaf again
+    uint32_t pad;
+};
+
+struct RayCtx
+{
+    float    ox, oy, oz, tmin, tmax;
+    float    Sx, Sy, Sz;  // shear of the watertight test
+    int      kz;
+    float    rnx, rny, rnz, cnx, cny, cnz;  // near planes: t = fma(plane, rn, cn)
+    float    rfx, rfy, rfz, cfx, cfy, cfz;  // far planes
+    uint32_t anx, any_, anz;                // byte offset of the near row of each axis; far row = offset ^ 16
 };
 
 PRT_DEV float sel3(float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); }
 
-PRT_DEV void ray_prepare(const BvhView& bvh, f3 o, f3 d, RayPre& r)
+PRT_DEV void ray_prepare(const BvhView& bvh, f3 o, float tmin, f3 d, float tmax, RayCtx& r)
 {
     r.ox = o.x; r.oy = o.y; r.oz = o.z;
+    r.tmin = tmin; r.tmax = tmax;
     int kz = 0;
     if(gabs(d.y) > gabs(sel3(d.x, d.y, d.z, kz))) kz = 1;
     if(gabs(d.z) > gabs(sel3(d.x, d.y, d.z, kz))) kz = 2;
     int kx = kz + 1; if(kx == 3) kx = 0;
     int ky = kx + 1; if(ky == 3) ky = 0;
+    // Woop et al. swap kx/ky when d[kz] < 0 to keep the winding; with two-sided triangles the swap only
+    // negates U, V, W, det and T together (every product is the same, every difference antisymmetric),
+    // so t = T/det, u = V/det, v = W/det and the sign tests come out bit-identical without it.
     const float dkz = sel3(d.x, d.y, d.z, kz);
-    if(dkz < 0.0f) { const int t = kx; kx = ky; ky = t; }
-    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.kz = kz;
     r.Sx = sel3(d.x, d.y, d.z, kx) / dkz;
     r.Sy = sel3(d.x, d.y, d.z, ky) / dkz;
     r.Sz = 1.0f / dkz;
@@ -80,60 +100,39 @@ PRT_DEV void ray_prepare(const BvhView& bvh, f3 o, f3 d, RayPre& r)
     amax       = gmax(amax, gabs(o.y));
     amax       = gmax(amax, gabs(o.z));
     const float pad = 3.814697265625e-06f * amax;
-#define PRT_SLAB_SETUP(c, on, of, rn, rf, ng)                        \
+#define PRT_SLAB_SETUP(c, rn, cn, rf, cf, an, row)                   \
     {                                                                \
         float dk = d.c;                                              \
         if(gabs(dk) < 1e-20f) dk = (dk < 0.0f) ? -1e-20f : 1e-20f;   \
-        const float rd = 1.0f / dk;                                  \
-        ng             = dk < 0.0f;                                  \
-        const float sp = ng ? -pad : pad;                            \
-        on             = o.c + sp;                                   \
-        of             = o.c - sp;                                   \
-        rn             = rd * 0.99999976f;                           \
-        rf             = rd * 1.00000024f;                           \
+        const float rd  = __builtin_amdgcn_rcpf(dk);                 \
+        const bool  ng  = dk < 0.0f;                                 \
+        const float sp  = ng ? -pad : pad;                           \
+        rn              = rd * 0.99999952f;                          \
+        rf              = rd * 1.00000048f;                          \
+        cn              = -((o.c + sp) * rn);                        \
+        cf              = -((o.c - sp) * rf);                        \
+        an              = (row) + (ng ? 16u : 0u);                   \
     }
-    PRT_SLAB_SETUP(x, r.onx, r.ofx, r.rnx, r.rfx, r.negx)
-    PRT_SLAB_SETUP(y, r.ony, r.ofy, r.rny, r.rfy, r.negy)
-    PRT_SLAB_SETUP(z, r.onz, r.ofz, r.rnz, r.rfz, r.negz)
+    PRT_SLAB_SETUP(x, r.rnx, r.cnx, r.rfx, r.cfx, r.anx, 0u)
+    PRT_SLAB_SETUP(y, r.rny, r.cny, r.rfy, r.cfy, r.any_, 32u)
+    PRT_SLAB_SETUP(z, r.rnz, r.cnz, r.rfz, r.cfz, r.anz, 64u)
 #undef PRT_SLAB_SETUP
 }
 
-PRT_DEV bool slab_test(const RayPre& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float tmin,
-                       float tbest, float& tnOut)
+PRT_DEV bool tri_test(const RayCtx& r, float4 q0, float4 q1, float4 q2, float& tOut, float& uOut, float& vOut)
 {
-    float tn = tmin, tf = tbest;
-    {
-        const float pn = r.negx ? mxx : mnx, pf = r.negx ? mnx : mxx;
-        tn = gmax(tn, (pn - r.onx) * r.rnx);
-        tf = gmin(tf, (pf - r.ofx) * r.rfx);
-    }
-    {
-        const float pn = r.negy ? mxy : mny, pf = r.negy ? mny : mxy;
-        tn = gmax(tn, (pn - r.ony) * r.rny);
-        tf = gmin(tf, (pf - r.ofy) * r.rfy);
-    }
-    {
-        const float pn = r.negz ? mxz : mnz, pf = r.negz ? mnz : mxz;
-        tn = gmax(tn, (pn - r.onz) * r.rnz);
-        tf = gmin(tf, (pf - r.ofz) * r.rfz);
-    }
-    tnOut = tn;
-    return tn <= tf;
-}
-
-PRT_DEV bool tri_test(const RayPre& r, float4 q0, float4 q1, float4 q2, float tmin, float tmax, float& tOut,
-                      float& uOut, float& vOut)
-{
+    int kx = r.kz + 1; if(kx == 3) kx = 0;
+    int ky = kx + 1; if(ky == 3) ky = 0;
     const float Ax_ = q0.x - r.ox, Ay_ = q0.y - r.oy, Az_ = q0.z - r.oz;
     const float Bx_ = q1.x - r.ox, By_ = q1.y - r.oy, Bz_ = q1.z - r.oz;
     const float Cx_ = q2.x - r.ox, Cy_ = q2.y - r.oy, Cz_ = q2.z - r.oz;
     const float Akz = sel3(Ax_, Ay_, Az_, r.kz), Bkz = sel3(Bx_, By_, Bz_, r.kz), Ckz = sel3(Cx_, Cy_, Cz_, r.kz);
-    const float Ax = sel3(Ax_, Ay_, Az_, r.kx) - r.Sx * Akz;
-    const float Ay = sel3(Ax_, Ay_, Az_, r.ky) - r.Sy * Akz;
-    const float Bx = sel3(Bx_, By_, Bz_, r.kx) - r.Sx * Bkz;
-    const float By = sel3(Bx_, By_, Bz_, r.ky) - r.Sy * Bkz;
-    const float Cx = sel3(Cx_, Cy_, Cz_, r.kx) - r.Sx * Ckz;
-    const float Cy = sel3(Cx_, Cy_, Cz_, r.ky) - r.Sy * Ckz;
+    const float Ax = sel3(Ax_, Ay_, Az_, kx) - r.Sx * Akz;
+    const float Ay = sel3(Ax_, Ay_, Az_, ky) - r.Sy * Akz;
+    const float Bx = sel3(Bx_, By_, Bz_, kx) - r.Sx * Bkz;
+    const float By = sel3(Bx_, By_, Bz_, ky) - r.Sy * Bkz;
+    const float Cx = sel3(Cx_, Cy_, Cz_, kx) - r.Sx * Ckz;
+    const float Cy = sel3(Cx_, Cy_, Cz_, ky) - r.Sy * Ckz;
     float       U  = Cx * By - Cy * Bx;
     float       V  = Ax * Cy - Ay * Cx;
     float       W  = Bx * Ay - By * Ax;
@@ -157,7 +156,7 @@ PRT_DEV bool tri_test(const RayPre& r, float4 q0, float4 q1, float4 q2, float tm
     const float T   = (U * Az + V * Bz) + W * Cz;
     const float rcp = 1.0f / det;
     const float t   = T * rcp;
-    if(!(t > tmin && t < tmax))
+    if(!(t > r.tmin && t < r.tmax))
         return false;
     tOut = t;
     uOut = V * rcp;
@@ -165,104 +164,292 @@ PRT_DEV bool tri_test(const RayPre& r, float4 q0, float4 q1, float4 q2, float tm
     return true;
 }
 
-// Per-lane stack: LDS [entry][thread] + scratch spill.
-struct LaneStack
-{
-    uint32_t* lds;  // &stackLds[threadIdx.x]
-    int32_t   spill[PRT_SPILL_STACK];
-    int       sp;
-    PRT_DEV void init(uint32_t* base) { lds = base; sp = 0; }
-    PRT_DEV void push(int32_t v)
-    {
-        if(sp < PRT_LDS_STACK)
-            lds[sp * PRT_TRACE_BLOCK] = (uint32_t)v;
-        else
-            spill[sp - PRT_LDS_STACK] = v;
-        ++sp;
-    }
-    PRT_DEV int32_t pop()
-    {
-        --sp;
-        return (sp < PRT_LDS_STACK) ? (int32_t)lds[sp * PRT_TRACE_BLOCK] : spill[sp - PRT_LDS_STACK];
-    }
-};
+// ---- per-lane stack: LDS [entry][thread] + scratch spill --------------------------------------------
+#define PRT_STACK_AT(lds, i) (lds)[(i) * PRT_TRACE_BLOCK]
 
-// ANY = true: terminate-on-first-hit / skip-closest-hit-shader occlusion query (returns prim != ~0u on hit).
-struct TraceCount
+PRT_DEV int32_t stack_pop(int& sp, const uint32_t* lds, const int32_t* spill)
 {
-    uint32_t nodes, tris;
-};
+    --sp;
+    if(__builtin_expect(sp < PRT_LDS_STACK, 1))
+        return (int32_t)PRT_STACK_AT(lds, sp);
+    asm volatile("" ::: "memory");  // keep the two loads in their own address spaces (no flat load)
+    return spill[sp - PRT_LDS_STACK];
+}
+PRT_DEV void stack_push_slow(int& sp, uint32_t* lds, int32_t* spill, int32_t v)
+{
+    if(sp < PRT_LDS_STACK)
+        PRT_STACK_AT(lds, sp) = (uint32_t)v;
+    else
+    {
+        asm volatile("" ::: "memory");
+        spill[sp - PRT_LDS_STACK] = v;
+    }
+    ++sp;
+}
 
-// INSTR = true additionally counts node visits and triangle tests (profiling level 2: the N_node / N_tri
-// of the algorithmic-bytes formula in DESIGN.md).
+#define PRT_CE(ta, ra, tb, rb)                     \
+    {                                              \
+        const bool    s_  = tb < ta;               \
+        const float   tl_ = s_ ? tb : ta;          \
+        const float   th_ = s_ ? ta : tb;          \
+        const int32_t rl_ = s_ ? rb : ra;          \
+        const int32_t rh_ = s_ ? ra : rb;          \
+        ta = tl_; tb = th_; ra = rl_; rb = rh_;    \
+    }
+
+// One BVH4 node: four slab tests, nearest hit child becomes `cur`, the others are pushed (farthest
+// first). No hit: pop. ANY rays skip the distance sort.
+template <bool ANY>
+PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_t& cur, int& sp, uint32_t* lds,
+                        int32_t* spill)
+{
+    const char*    nb   = (const char*)bvh.nodes;
+    const uint32_t base = (uint32_t)cur << 7;
+    const float4   nx   = *(const float4*)(nb + (base + r.anx));
+    const float4   fx   = *(const float4*)(nb + (base + (r.anx ^ 16u)));
+    const float4   ny   = *(const float4*)(nb + (base + r.any_));
+    const float4   fy   = *(const float4*)(nb + (base + (r.any_ ^ 16u)));
+    const float4   nz   = *(const float4*)(nb + (base + r.anz));
+    const float4   fz   = *(const float4*)(nb + (base + (r.anz ^ 16u)));
+    const float4   cq   = *(const float4*)(nb + (base + 96u));
+    const float    inf  = __builtin_inff();
+#define PRT_SLAB(j, key)                                                                                             \
+    {                                                                                                                \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(nx.j, r.rnx, r.cnx),                        \
+                                                         __builtin_fmaf(ny.j, r.rny, r.cny)),                       \
+                                         __builtin_fmaxf(__builtin_fmaf(nz.j, r.rnz, r.cnz), r.tmin));              \
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(fx.j, r.rfx, r.cfx),                        \
+                                                         __builtin_fmaf(fy.j, r.rfy, r.cfy)),                       \
+                                         __builtin_fminf(__builtin_fmaf(fz.j, r.rfz, r.cfz), tbest));               \
+        key = (tn <= tf) ? tn : inf;                                                                                 \
+    }
+    float t0, t1, t2, t3;
+    PRT_SLAB(x, t0)
+    PRT_SLAB(y, t1)
+    PRT_SLAB(z, t2)
+    PRT_SLAB(w, t3)
+#undef PRT_SLAB
+    int32_t r0 = __float_as_int(cq.x), r1 = __float_as_int(cq.y), r2 = __float_as_int(cq.z), r3 = __float_as_int(cq.w);
+    if(!ANY)
+    {
+        PRT_CE(t0, r0, t1, r1)
+        PRT_CE(t2, r2, t3, r3)
+        PRT_CE(t0, r0, t2, r2)
+        PRT_CE(t1, r1, t3, r3)
+        PRT_CE(t1, r1, t2, r2)
+    }
+    const bool v0 = t0 < inf, v1 = t1 < inf, v2 = t2 < inf, v3 = t3 < inf;
+    if(__builtin_expect(sp + 3 <= PRT_LDS_STACK, 1))
+    {
+        PRT_STACK_AT(lds, sp) = (uint32_t)r3;
+        sp += v3 ? 1 : 0;
+        PRT_STACK_AT(lds, sp) = (uint32_t)r2;
+        sp += v2 ? 1 : 0;
+        PRT_STACK_AT(lds, sp) = (uint32_t)r1;
+        sp += v1 ? 1 : 0;
+    }
+    else
+    {
+        if(v3) stack_push_slow(sp, lds, spill, r3);
+        if(v2) stack_push_slow(sp, lds, spill, r2);
+        if(v1) stack_push_slow(sp, lds, spill, r1);
+    }
+    if(v0)
+        cur = r0;
+    else
+        cur = stack_pop(sp, lds, spill);
+}
+
+// All triangles of one leaf. Returns true when an ANY ray found an occluder.
+template <bool ANY, bool INSTR>
+PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit& best, TraceCount& tc)
+{
+    const uint32_t ref   = ~(uint32_t)leafRef;
+    const uint32_t first = ref >> 3, count = ref & 7u;
+    const float4*  t     = bvh.tris + (size_t)first * 3;
+    for(uint32_t i = 0; i < count; ++i)
+    {
+        const float4 a = t[3 * i], b = t[3 * i + 1], c = t[3 * i + 2];
+        float        tt, uu, vv;
+        if(INSTR) tc.tris++;
+        if(tri_test(r, a, b, c, tt, uu, vv))
+        {
+            const uint32_t p = (uint32_t)__float_as_int(a.w);
+            if(ANY)
+            {
+                best.prim = p;
+                best.t    = tt;
+                return true;
+            }
+            if(tt < best.t || (tt == best.t && p < best.prim))
+            {
+                best.t    = tt;
+                best.u    = uu;
+                best.v    = vv;
+                best.prim = p;
+            }
+        }
+    }
+    return false;
+}
+
+PRT_DEV Hit hit_none(float tmax)
+{
+    Hit h;
+    h.prim = 0xffffffffu;
+    h.u = h.v = 0.0f;
+    h.t       = tmax;
+    return h;
+}
+
+// ---- one ray per lane, all lanes start together (AO rays inside k_ao_shade) ---------------------------
+// ANY = true: terminate-on-first-hit / skip-closest-hit-shader occlusion query (prim != ~0u on hit).
+// INSTR = true additionally counts node visits and triangle tests (profiling level 2).
 template <bool ANY, bool INSTR = false>
-PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* ldsStack, f3 o, float tmin, f3 d, float tmax,
-                      TraceCount* tc = nullptr)
+PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, f3 o, float tmin, f3 d, float tmax, TraceCount* tcp = nullptr)
 {
-    RayPre r;
-    ray_prepare(bvh, o, d, r);
-    Hit best;
-    best.prim = 0xffffffffu;
-    best.u = best.v = 0.0f;
-    best.t          = tmax;
-    LaneStack st;
-    st.init(ldsStack);
+    RayCtx r;
+    ray_prepare(bvh, o, tmin, d, tmax, r);
+    Hit        best = hit_none(tmax);
+    TraceCount tc   = {0u, 0u};
+    int32_t    spill[PRT_SPILL_STACK];
+    PRT_STACK_AT(lds, 0) = (uint32_t)kSentinel;
+    int     sp  = 1;
     int32_t cur = bvh.root;
-    for(;;)
+    while(cur != kSentinel)
     {
         if(cur >= 0)
         {
-            const float4* n  = bvh.nodes + (size_t)cur * 4;
-            if(INSTR) tc->nodes++;
-            const float4  q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-            float         tl, tr;
-            const bool    hl = slab_test(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, tmin, best.t, tl);
-            const bool    hr = slab_test(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, tmin, best.t, tr);
-            const int32_t li = __float_as_int(q0.w), ri = __float_as_int(q1.w);
-            if(hl && hr)
-            {
-                const bool rightFirst = tr < tl;
-                st.push(rightFirst ? li : ri);
-                cur = rightFirst ? ri : li;
-                continue;
-            }
-            if(hl) { cur = li; continue; }
-            if(hr) { cur = ri; continue; }
+            if(INSTR) tc.nodes++;
+            node4_step<ANY>(bvh, r, best.t, cur, sp, lds, spill);
         }
         else
         {
-            const uint32_t ref   = ~(uint32_t)cur;
-            const uint32_t first = ref >> 3, count = ref & 7u;
-            const float4*  t     = bvh.tris + (size_t)first * 3;
-            for(uint32_t i = 0; i < count; ++i)
+            if(leaf_test<ANY, INSTR>(bvh, r, cur, best, tc)) break;
+            cur = stack_pop(sp, lds, spill);
+        }
+    }
+    if(INSTR && tcp)
+    {
+        tcp->nodes += tc.nodes;
+        tcp->tris += tc.tris;
+    }
+    return best;
+}
+
+// ---- persistent wave: a stream of `count` rays ----------------------------------------------------------
+// IO::load(i, o, tmin, d, tmax, tag) -> bool (true: the ray counts in the statistics);
+// IO::store(tag, hit) is called once per ray when it has finished.
+template <bool ANY, bool INSTR, class IO>
+PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uint32_t* workCtr, const TraceTune tune,
+                          IO& io, uint32_t& nrays, TraceCount& tc)
+{
+    const int                lane   = threadIdx.x & 63;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    uint32_t                 chunkPos = 0, chunkEnd = 0;  // wave-uniform
+    bool                     exhausted = false;
+    bool                     active    = false;
+    int32_t                  cur = kSentinel, leaf = kEmptyLeaf;
+    int                      sp = 1;
+    int32_t                  spill[PRT_SPILL_STACK];
+    RayCtx                   r;
+    Hit                      best = hit_none(0.0f);
+    uint32_t                 tag  = 0;
+    r.tmin = r.tmax = 0.0f;
+    PRT_STACK_AT(lds, 0) = (uint32_t)kSentinel;  // bottom of the lane's stack; sp >= 1 always
+
+    for(uint32_t guard = 0; guard < (1u << 24); ++guard)
+    {
+        // ---- refill idle lanes from the queue
+        const unsigned long long idleMask = __ballot(!active);
+        const uint32_t           nIdle    = (uint32_t)__popcll(idleMask);
+        if(!exhausted && nIdle >= tune.refillMin)
+        {
+            if(chunkPos == chunkEnd)
             {
-                const float4 a = t[3 * i], b = t[3 * i + 1], c = t[3 * i + 2];
-                float        tt, uu, vv;
-                if(INSTR) tc->tris++;
-                if(tri_test(r, a, b, c, tmin, tmax, tt, uu, vv))
+                uint32_t b = 0;
+                if(lane == 0) b = atomicAdd(workCtr, PRT_CHUNK);
+                b        = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                chunkPos = b < count ? b : count;
+                chunkEnd = (count - chunkPos) < PRT_CHUNK ? count : chunkPos + PRT_CHUNK;
+                if(chunkPos == chunkEnd) exhausted = true;
+            }
+            const uint32_t avail = chunkEnd - chunkPos;
+            const uint32_t take  = nIdle < avail ? nIdle : avail;
+            const uint32_t rank  = (uint32_t)__popcll(idleMask & ltMask);
+            if(!active && rank < take)
+            {
+                f3    o, d;
+                float tmin, tmax;
+                if(io.load(chunkPos + rank, o, tmin, d, tmax, tag)) nrays++;
+                ray_prepare(bvh, o, tmin, d, tmax, r);
+                best   = hit_none(tmax);
+                cur    = bvh.root;
+                leaf   = kEmptyLeaf;
+                sp     = 1;
+                active = true;
+            }
+            chunkPos += take;
+        }
+        const uint32_t nActive = (uint32_t)__popcll(__ballot(active));
+        if(nActive == 0)
+        {
+            if(exhausted) break;
+            continue;
+        }
+
+        // ---- node phase: every lane at an inner node steps; a lane that reaches its first leaf postpones
+        //      it and keeps descending; lanes at a second leaf (or finished) wait
+        for(;;)
+        {
+            if(active && (uint32_t)cur < (uint32_t)kSentinel)
+            {
+                if(INSTR) tc.nodes++;
+                node4_step<ANY>(bvh, r, best.t, cur, sp, lds, spill);
+                if(cur < 0 && leaf == kEmptyLeaf)
                 {
-                    const uint32_t p = (uint32_t)__float_as_int(a.w);
-                    if(ANY)
-                    {
-                        best.prim = p;
-                        best.t    = tt;
-                        return best;
-                    }
-                    if(tt < best.t || (tt == best.t && p < best.prim))
-                    {
-                        best.t    = tt;
-                        best.u    = uu;
-                        best.v    = vv;
-                        best.prim = p;
-                    }
+                    leaf = cur;
+                    cur  = stack_pop(sp, lds, spill);
+                }
+            }
+            const uint32_t nProd = (uint32_t)__popcll(__ballot(active && (uint32_t)cur < (uint32_t)kSentinel));
+            if(nProd == 0 || nActive - nProd > tune.stallMax) break;
+        }
+
+        // ---- triangle phase
+        if(active && leaf == kEmptyLeaf && cur < 0)
+        {
+            leaf = cur;
+            cur  = stack_pop(sp, lds, spill);
+        }
+        for(uint32_t round = 0;; ++round)
+        {
+            const uint32_t nLeaf = (uint32_t)__popcll(__ballot(active && leaf != kEmptyLeaf));
+            if(nLeaf == 0 || (round > 0 && nLeaf < tune.leafMin)) break;
+            if(active && leaf != kEmptyLeaf)
+            {
+                const bool occluded = leaf_test<ANY, INSTR>(bvh, r, leaf, best, tc);
+                leaf                = kEmptyLeaf;
+                if(ANY && occluded)
+                {
+                    cur = kSentinel;
+                    sp  = 1;
+                }
+                else if(cur < 0)
+                {
+                    leaf = cur;
+                    cur  = stack_pop(sp, lds, spill);
                 }
             }
         }
-        if(st.sp == 0)
-            break;
-        cur = st.pop();
+
+        // ---- finished rays
+        if(active && cur == kSentinel && leaf == kEmptyLeaf)
+        {
+            io.store(tag, best);
+            active = false;
+        }
     }
-    return best;
 }
 
 }  // namespace prt
