@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprt_hip.so")
+LIB_PATH = os.environ.get("PRT_LIB") or os.path.join(_HERE, "libprt_hip.so")  # PRT_LIB: measurement builds only
 
 MODE_PATH, MODE_AO = 0, 1
 FLAG_LITERAL, FLAG_RUSSIAN_ROULETTE = 1, 2

@@ -27,6 +27,7 @@ struct prt_context
     uint32_t    w = 0, h = 0, npix = 0;
     uint32_t    flags = 0, seed = 1;
     int         numCU = 256;
+    uint32_t    gridExtend = 0, gridShadow = 0, gridBatch = 0, gridAo = 0;  // resident blocks of the persistent kernels
     std::string err;
 
     // scene
@@ -41,7 +42,8 @@ struct prt_context
     // acceleration structure
     BuildNode* dBuildNodes = nullptr;
     uint32_t*  dOrder      = nullptr;
-    float4*    dNodes      = nullptr;  // BVH4, 8 x float4 per node
+    uint4*     dNodes      = nullptr;  // BVH4, 4 x uint4 per node
+    QuantGrid  grid{};
     float4*    dTris       = nullptr;
     uint32_t   nNodes = 0, nInner = 0, depth = 0;
     int32_t    root     = 0;
@@ -181,6 +183,24 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
     hipDeviceProp_t prop;
     if(e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if(e == hipSuccess) c->numCU = prop.multiProcessorCount;
+    if(e == hipSuccess)
+    {
+        // persistent kernels: exactly as many blocks as stay resident
+        auto resident = [&](const void* fn) -> uint32_t {
+            int nb = 0;
+            if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, PRT_TRACE_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+            return (uint32_t)nb * (uint32_t)c->numCU;
+        };
+        c->gridExtend = resident((const void*)k_extend<false>);
+        c->gridShadow = resident((const void*)k_shadow<false>);
+        c->gridBatch  = resident((const void*)k_trace_batch<false>);
+        c->gridAo     = resident((const void*)k_ao_shade);
+        if(const char* g = getenv("PRT_GRID_BLOCKS_PER_CU"))
+        {
+            const int nb = atoi(g);
+            if(nb >= 1 && nb <= 16) c->gridExtend = c->gridShadow = c->gridBatch = c->gridAo = (uint32_t)nb * (uint32_t)c->numCU;
+        }
+    }
     const size_t n = c->npix;
     if(e == hipSuccess) e = dalloc(c->accumOwn, n);
     if(e == hipSuccess) e = dalloc(c->rayO, n);
@@ -420,25 +440,10 @@ int prt_build_accel(prt_context* c)
     if(orderCur != c->dOrder)
         BCHK(hipMemcpyAsync(c->dOrder, orderCur, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
 
-    // traversal layout: BVH4 (see prt_bvh.hpp)
-    hipLaunchKernelGGL(k_wide_flags, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, lt, flags);
-    rc = device_scan(c, flags, nNodes, tileSums, total);
-    if(rc) { cleanup(); return rc; }
-    uint32_t nInner = 0;
-    BCHK(hipMemcpyAsync(&nInner, total, 4, hipMemcpyDeviceToHost, st));
-    BCHK(hipStreamSynchronize(st));
-    if(nInner >= (1u << 25)) { cleanup(); return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^25 BVH4 nodes"); }
-    BCHK(dalloc(c->dNodes, (size_t)(nInner ? nInner : 1) * 8));
-    BCHK(dalloc(c->dTris, (size_t)3 * N));
-    hipLaunchKernelGGL(k_emit_wide, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, lt, flags,
-                       c->dNodes);
-    hipLaunchKernelGGL(k_emit_tris, dim3(cdiv(N, 256)), dim3(256), 0, st, c->dVerts, c->dIdx, c->dOrder, N, c->dTris);
-    BCHK(hipGetLastError());
+    // traversal layout: BVH4 with 16-bit boxes on the root box (see prt_bvh.hpp)
     BuildNode rootNode;
     BCHK(hipMemcpyAsync(&rootNode, c->dBuildNodes, sizeof rootNode, hipMemcpyDeviceToHost, st));
     BCHK(hipStreamSynchronize(st));
-    cleanup();
-#undef BCHK
     auto dec = [](uint32_t k) {
         const uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
         float          f;
@@ -448,10 +453,29 @@ int prt_build_accel(prt_context* c)
     float sa = 0.0f;
     for(int k = 0; k < 3; ++k)
     {
-        const float a = fabsf(dec(rootNode.bmin[k])), b = fabsf(dec(rootNode.bmax[k]));
-        sa            = sa < a ? a : sa;
-        sa            = sa < b ? b : sa;
+        const float lo = dec(rootNode.bmin[k]), hi = dec(rootNode.bmax[k]);
+        sa             = sa < fabsf(lo) ? fabsf(lo) : sa;
+        sa             = sa < fabsf(hi) ? fabsf(hi) : sa;
+        const float ext = hi - lo;
+        c->grid.qmin[k]   = lo;
+        c->grid.qscale[k] = ext > 0.0f ? (ext / 65535.0f) * 1.0001f : 1.0f;  // qmin + 65535*scale >= hi
     }
+    hipLaunchKernelGGL(k_wide_flags, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, lt, flags);
+    rc = device_scan(c, flags, nNodes, tileSums, total);
+    if(rc) { cleanup(); return rc; }
+    uint32_t nInner = 0;
+    BCHK(hipMemcpyAsync(&nInner, total, 4, hipMemcpyDeviceToHost, st));
+    BCHK(hipStreamSynchronize(st));
+    if(nInner >= (1u << 26)) { cleanup(); return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^26 BVH4 nodes"); }
+    BCHK(dalloc(c->dNodes, (size_t)(nInner ? nInner : 1) * 4));
+    BCHK(dalloc(c->dTris, (size_t)3 * N));
+    hipLaunchKernelGGL(k_emit_wide, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, lt, flags,
+                       c->grid, c->dNodes);
+    hipLaunchKernelGGL(k_emit_tris, dim3(cdiv(N, 256)), dim3(256), 0, st, c->dVerts, c->dIdx, c->dOrder, N, c->dTris);
+    BCHK(hipGetLastError());
+    BCHK(hipStreamSynchronize(st));
+    cleanup();
+#undef BCHK
     c->sceneAbs  = sa;
     c->nNodes    = nNodes;
     c->nInner    = nInner;
@@ -573,6 +597,11 @@ static void make_views(prt_context* c, SceneView& sc, FrameView& f)
     sc.bvh.tris     = c->dTris;
     sc.bvh.root     = c->root;
     sc.bvh.sceneAbs = c->sceneAbs;
+    for(int k = 0; k < 3; ++k)
+    {
+        sc.bvh.qmin[k]   = c->grid.qmin[k];
+        sc.bvh.qscale[k] = c->grid.qscale[k];
+    }
     f.w             = c->w;
     f.h             = c->h;
     f.npix          = c->npix;
@@ -622,7 +651,6 @@ static int render_one(prt_context* c, int mode)
     *hU = c->ubo;
     HIPCHK(c, hipMemcpyAsync(dU, hU, sizeof(prt_uniforms), hipMemcpyHostToDevice, st));
     const uint32_t gridPix   = cdiv(c->npix, 256);
-    const uint32_t gridTrace = (uint32_t)c->numCU * 6u;
     const uint32_t gridShade = (uint32_t)c->numCU * 8u;
     if(mode == PRT_MODE_AO)
     {
@@ -631,10 +659,10 @@ static int render_one(prt_context* c, int mode)
             ProfScope ps(c, PRT_K_GENERATE);
             hipLaunchKernelGGL(k_ao_generate, dim3(gridPix), dim3(256), 0, st, f, (const prt_uniforms*)dU, c->flags);
         }
-        launch_extend(c, sc, f, gridTrace, nullptr, nullptr, c->counters + 0, 1u);
+        launch_extend(c, sc, f, c->gridExtend, nullptr, nullptr, c->counters + 0, 1u);
         {
             ProfScope ps(c, PRT_K_AO_SHADE);
-            hipLaunchKernelGGL(k_ao_shade, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+            hipLaunchKernelGGL(k_ao_shade, dim3(c->gridAo), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
                                (const prt_uniforms*)dU, c->flags, c->counters + 1);
         }
         HIPCHK(c, hipGetLastError());
@@ -658,7 +686,7 @@ static int render_one(prt_context* c, int mode)
             const uint32_t* qIn  = b == 0 ? nullptr : c->q[b & 1];
             const uint32_t* nIn  = b == 0 ? nullptr : c->counters + b;
             uint32_t*       qOut = c->q[(b + 1) & 1];
-            launch_extend(c, sc, f, gridTrace, qIn, nIn, c->counters + 64 + b, b == 0 ? 1u : 0u);
+            launch_extend(c, sc, f, c->gridExtend, qIn, nIn, c->counters + 64 + b, b == 0 ? 1u : 0u);
             {
                 ProfScope ps(c, PRT_K_SHADE);
                 hipLaunchKernelGGL(k_shade, dim3(gridShade), dim3(256), 0, st, sc, f, (const prt_uniforms*)dU, fl,
@@ -668,11 +696,11 @@ static int render_one(prt_context* c, int mode)
             {
                 ProfScope ps(c, PRT_K_SHADOW);
                 if(c->profLevel >= 2)
-                    hipLaunchKernelGGL(k_shadow<true>, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+                    hipLaunchKernelGGL(k_shadow<true>, dim3(c->gridShadow), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
                                        (const uint32_t*)c->qShadow, (const uint32_t*)(c->counters + 32 + b),
                                        c->counters + 128 + b, trace_tune());
                 else
-                    hipLaunchKernelGGL(k_shadow<false>, dim3(gridTrace), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+                    hipLaunchKernelGGL(k_shadow<false>, dim3(c->gridShadow), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
                                        (const uint32_t*)c->qShadow, (const uint32_t*)(c->counters + 32 + b),
                                        c->counters + 128 + b, trace_tune());
             }
@@ -849,7 +877,7 @@ int prt_trace_device(prt_context* c, const void* rays, size_t n, int any, void* 
     HIPCHK(c, hipEventCreate(&e1));
     // counters[192]: work-fetch cursor of this launch (the render passes use words 0..191)
     uint32_t*      work = c->counters + 192;
-    const uint32_t grid = (uint32_t)c->numCU * 6u;
+    const uint32_t grid = c->gridBatch;
     HIPCHK(c, hipMemsetAsync(work, 0, 4, c->stream));
     HIPCHK(c, hipEventRecord(e0, c->stream));
     if(any)

@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ or
 // A wide node is made from every inner build node on an EVEN level: its slots are its grandchildren
 // (children that are leaves stay as they are), in left-to-right order. Child reference: >= 0 index of a
 // wide node, < 0 ~((first << 3) | count) for a leaf over tris[first .. first+count); empty slots carry an
-// inverted box (min = +inf, max = -inf) that no ray enters.
+// inverted box that no ray enters. Boxes are stored as 16-bit fixed point on the root box, rounded outwards.
 struct LevelTable
 {
     uint32_t start[PRT_MAX_DEPTH + 2];  // first build-node index of every level (levels are contiguous)
@@ -512,9 +512,31 @@ __global__ void __launch_bounds__(256) k_wide_flags(const BuildNode* __restrict_
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i < nnodes) flags[i] = (nodes[i].count == 0 && (level_of(lt, i) & 1u) == 0u) ? 1u : 0u;
 }
+struct QuantGrid
+{
+    float qmin[3], qscale[3];  // coordinate = qmin + q * qscale
+};
+// largest q with qmin + q*scale <= v / smallest q with qmin + q*scale >= v, exact in fp64
+// (q*scale and the sum are exact in double: 16 x 24 bits, then < 53 bits)
+PRT_DEV uint32_t quant_floor(float v, float qmin, float scale)
+{
+    double q = __builtin_floor(((double)v - (double)qmin) / (double)scale);
+    if(q < 0.0) q = 0.0;
+    if(q > 65535.0) q = 65535.0;
+    while(q > 0.0 && (double)qmin + q * (double)scale > (double)v) q -= 1.0;
+    return (uint32_t)q;
+}
+PRT_DEV uint32_t quant_ceil(float v, float qmin, float scale)
+{
+    double q = __builtin_ceil(((double)v - (double)qmin) / (double)scale);
+    if(q < 0.0) q = 0.0;
+    if(q > 65535.0) q = 65535.0;
+    while(q < 65535.0 && (double)qmin + q * (double)scale < (double)v) q += 1.0;
+    return (uint32_t)q;
+}
 __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__ nodes, uint32_t nnodes,
-                                                   LevelTable lt, const uint32_t* __restrict__ wideIdx,
-                                                   float4* __restrict__ out)
+                                                   LevelTable lt, const uint32_t* __restrict__ wideIdx, QuantGrid g,
+                                                   uint4* __restrict__ out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= nnodes || nodes[i].count != 0 || (level_of(lt, i) & 1u) != 0u) return;
@@ -530,8 +552,8 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
         else
             slot[n++] = c;
     }
-    float   mn[3][4], mx[3][4];
-    int32_t ref[4];
+    uint32_t qmn[3][4], qmx[3][4];
+    int32_t  ref[4];
     for(int j = 0; j < 4; ++j)
     {
         if(j < n)
@@ -539,29 +561,27 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
             const BuildNode c = nodes[slot[j]];
             for(int k = 0; k < 3; ++k)
             {
-                mn[k][j] = fdec(c.bmin[k]);
-                mx[k][j] = fdec(c.bmax[k]);
+                qmn[k][j] = quant_floor(fdec(c.bmin[k]), g.qmin[k], g.qscale[k]);
+                qmx[k][j] = quant_ceil(fdec(c.bmax[k]), g.qmin[k], g.qscale[k]);
             }
             ref[j] = c.count == 0 ? (int32_t)wideIdx[slot[j]] : (int32_t)~((c.first << 3) | c.count);
         }
         else
         {
+            // empty slot: inverted box; should a ray still "enter" it (flat scene), the reference is an empty leaf
             for(int k = 0; k < 3; ++k)
             {
-                mn[k][j] = __builtin_inff();
-                mx[k][j] = -__builtin_inff();
+                qmn[k][j] = 65535u;
+                qmx[k][j] = 0u;
             }
             ref[j] = -1;
         }
     }
-    float4* o = out + (size_t)wideIdx[i] * 8;
+    uint4* o = out + (size_t)wideIdx[i] * 4;
     for(int k = 0; k < 3; ++k)
-    {
-        o[2 * k]     = make_float4(mn[k][0], mn[k][1], mn[k][2], mn[k][3]);
-        o[2 * k + 1] = make_float4(mx[k][0], mx[k][1], mx[k][2], mx[k][3]);
-    }
-    o[6] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(ref[2]), __int_as_float(ref[3]));
-    o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        o[k] = make_uint4(qmn[k][0] | (qmn[k][1] << 16), qmn[k][2] | (qmn[k][3] << 16), qmx[k][0] | (qmx[k][1] << 16),
+                          qmx[k][2] | (qmx[k][3] << 16));
+    o[3] = make_uint4((uint32_t)ref[0], (uint32_t)ref[1], (uint32_t)ref[2], (uint32_t)ref[3]);
 }
 __global__ void __launch_bounds__(256) k_emit_tris(const prt_vertex* __restrict__ verts,
                                                    const uint32_t* __restrict__ idx,

@@ -62,6 +62,23 @@ PRT_DEV void  mul44(const float* __restrict__ m, float x, float y, float z, floa
     out[3] = (m[3] * x + m[7] * y) + (m[11] * z + m[15] * w);
 }
 
+// Streaming (read-once / write-once) per-ray records: non-temporal, so that they do not push the BVH out of L2.
+typedef float    v4f_t __attribute__((ext_vector_type(4)));
+typedef uint32_t v1u_t;
+PRT_DEV float4 ld_nt(const float4* p)
+{
+    const v4f_t v = __builtin_nontemporal_load((const v4f_t*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+PRT_DEV void st_nt(float4* p, float4 q)
+{
+    v4f_t v;
+    v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w;
+    __builtin_nontemporal_store(v, (v4f_t*)p);
+}
+PRT_DEV uint32_t ld_nt(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+PRT_DEV void     st_nt(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+
 constexpr float kPi = 3.141592653589f;  // pathRT.rgen:85
 
 // sin/cos with a fixed polynomial: Cody-Waite reduction by pi/2 + single-precision minimax kernels.

@@ -173,8 +173,8 @@ struct ExtendIO
     uint32_t         primary;
     PRT_DEV bool load(uint32_t i, f3& o, float& tmin, f3& d, float& tmax, uint32_t& tag) const
     {
-        const uint32_t px = queue ? queue[i] : i;
-        const float4   oq = f.rayO[px], dq = f.rayD[px];
+        const uint32_t px = queue ? ld_nt(queue + i) : i;
+        const float4   oq = ld_nt(f.rayO + px), dq = ld_nt(f.rayD + px);
         o    = mk3(oq.x, oq.y, oq.z);
         tmin = oq.w;
         d    = mk3(dq.x, dq.y, dq.z);
@@ -184,13 +184,13 @@ struct ExtendIO
     }
     PRT_DEV void store(uint32_t px, const Hit& h) const
     {
-        f.hit[px] = make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t);
-        if(primary) f.hitIds[px] = h.prim;
+        st_nt(f.hit + px, make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t));
+        if(primary) st_nt(f.hitIds + px, h.prim);
     }
 };
 
 template <bool INSTR>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_extend(SceneView sc, FrameView f, const uint32_t* __restrict__ queue,
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_extend(SceneView sc, FrameView f, const uint32_t* __restrict__ queue,
                                                             const uint32_t* __restrict__ countPtr,
                                                             uint32_t* workCtr, uint32_t primary, TraceTune tune)
 {
@@ -492,8 +492,8 @@ struct ShadowIO
     const uint32_t*  queue;
     PRT_DEV bool load(uint32_t i, f3& o, float& tmin, f3& d, float& tmax, uint32_t& tag) const
     {
-        const uint32_t px = queue[i];
-        const float4   oq = f.shO[px], dq = f.shD[px];
+        const uint32_t px = ld_nt(queue + i);
+        const float4   oq = ld_nt(f.shO + px), dq = ld_nt(f.shD + px);
         o    = mk3(oq.x, oq.y, oq.z);
         tmin = 0.000001f;
         d    = mk3(dq.x, dq.y, dq.z);
@@ -503,14 +503,14 @@ struct ShadowIO
     }
     PRT_DEV void store(uint32_t px, const Hit& h) const
     {
-        const float4 Ei = (h.prim != 0xffffffffu) ? f.eiOcc[px] : f.eiVis[px];
-        const float4 E  = f.accum[px];
-        f.accum[px]     = make_float4(E.x + Ei.x, E.y + Ei.y, E.z + Ei.z, E.w + f.shO[px].w);
+        const float4 Ei = (h.prim != 0xffffffffu) ? ld_nt(f.eiOcc + px) : ld_nt(f.eiVis + px);
+        const float4 E  = ld_nt(f.accum + px);
+        st_nt(f.accum + px, make_float4(E.x + Ei.x, E.y + Ei.y, E.z + Ei.z, E.w + ld_nt(f.shO + px).w));
     }
 };
 
 template <bool INSTR>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_shadow(SceneView sc, FrameView f,
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_shadow(SceneView sc, FrameView f,
                                                             const uint32_t* __restrict__ queue,
                                                             const uint32_t* __restrict__ countPtr, uint32_t* workCtr,
                                                             TraceTune tune)
@@ -656,7 +656,7 @@ struct BatchIO
     }
 };
 template <bool ANY>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_trace_batch(BvhView bvh, const float4* __restrict__ rays,
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_trace_batch(BvhView bvh, const float4* __restrict__ rays,
                                                                  uint32_t n, float4* __restrict__ hits,
                                                                  uint32_t* workCtr, TraceTune tune)
 {

@@ -1,10 +1,11 @@
 // prt_trace.hpp — wave64 BVH traversal for gfx950: replaces traceNV / the RT cores
 // (shaders/pathRT.rgen:692,819-822,963; shaders/AO.rgen:215,259-262).
 //
-// * BVH4, 128-byte nodes (one HBM/L2 line): six rows of four floats (min x, max x, min y, max y, min z,
-//   max z of the four children) + one row of four child references. A ray picks the near / far row of
-//   each axis BY ADDRESS (row offset ^ 16 from the sign of its direction), so the slab test has no
-//   per-child selects: one fma per plane, v_max3/v_min3 for the interval.
+// * BVH4, 64-byte nodes (two per HBM/L2 line), four 16-byte loads per visit: the child boxes are 16-bit
+//   fixed point on the scene's bounding box (rounded outwards; one row per axis: min[4] | max[4]) + one
+//   row of four child references. The traversal kernels are bound by the vector-memory pipeline
+//   (TA/TCP: random 16-byte requests), not by VALU or HBM, so bytes and loads per visit are what counts;
+//   the de-quantisation folds into the per-ray slab constants: t = fma(float(q), r*scale, c').
 // * Leaves reference runs of <= 4 pre-gathered triangles, 48 bytes each (3 x float4, prim id in
 //   v0.w), laid out in leaf order so a leaf is one contiguous 48..192-byte read.
 // * Per-lane traversal stack: the first PRT_LDS_STACK entries live in LDS, laid out [entry][lane] so
@@ -26,24 +27,30 @@
 
 namespace prt {
 
+#ifndef PRT_LDS_STACK
 #define PRT_LDS_STACK 24
+#endif
 #define PRT_SPILL_STACK 80
 #define PRT_MAX_DEPTH 64  // depth limit of the binary build tree (=> <= 33 BVH4 levels, <= 100 stack entries)
 #define PRT_TRACE_BLOCK 256
-#define PRT_NODE_BYTES 128
+#ifndef PRT_TRACE_WAVES
+#define PRT_TRACE_WAVES 4  // minimum waves per SIMD the traversal kernels are compiled for
+#endif
+#define PRT_NODE_BYTES 64
 #define PRT_CHUNK 128u
 
-static_assert(1 + 3 * (PRT_MAX_DEPTH / 2 + 1) <= PRT_LDS_STACK + PRT_SPILL_STACK, "stack covers the deepest tree");
+static_assert(1 + 3 * (PRT_MAX_DEPTH / 2 + 1) <= 24 + PRT_SPILL_STACK && PRT_LDS_STACK >= 8, "stack covers the deepest tree");
 
 constexpr int32_t kSentinel  = 0x7fffffff;  // bottom-of-stack marker: the ray is finished
 constexpr int32_t kEmptyLeaf = -1;          // ~0: leaf reference with count 0
 
 struct BvhView
 {
-    const float4* nodes;  // 8 x float4 per BVH4 node
+    const uint4*  nodes;  // 4 x uint4 per BVH4 node
     const float4* tris;   // 3 x float4 per triangle, leaf order
     int32_t       root;   // node index (0), or a leaf reference when the scene has <= 4 triangles
     float         sceneAbs;
+    float         qmin[3], qscale[3];  // box coordinate = qmin + q * qscale, q in [0, 65535]
 };
 
 struct Hit
@@ -71,9 +78,9 @@ struct RayCtx
     float    ox, oy, oz, tmin, tmax;
     float    Sx, Sy, Sz;  // shear of the watertight test
     int      kz;
-    float    rnx, rny, rnz, cnx, cny, cnz;  // near planes: t = fma(plane, rn, cn)
+    float    rnx, rny, rnz, cnx, cny, cnz;  // near planes: t = fma(float(q), rn, cn)
     float    rfx, rfy, rfz, cfx, cfy, cfz;  // far planes
-    uint32_t anx, any_, anz;                // byte offset of the near row of each axis; far row = offset ^ 16
+    bool     negx, negy, negz;              // direction sign: the near plane is max instead of min
 };
 
 PRT_DEV float sel3(float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); }
@@ -100,22 +107,24 @@ PRT_DEV void ray_prepare(const BvhView& bvh, f3 o, float tmin, f3 d, float tmax,
     amax       = gmax(amax, gabs(o.y));
     amax       = gmax(amax, gabs(o.z));
     const float pad = 3.814697265625e-06f * amax;
-#define PRT_SLAB_SETUP(c, rn, cn, rf, cf, an, row)                   \
+    // plane distance t = (qmin + q*qscale - (o +- pad)) * rd, widened by 2^-21, as one fma on float(q)
+#define PRT_SLAB_SETUP(c, k, rn, cn, rf, cf, ng)                     \
     {                                                                \
         float dk = d.c;                                              \
         if(gabs(dk) < 1e-20f) dk = (dk < 0.0f) ? -1e-20f : 1e-20f;   \
         const float rd  = __builtin_amdgcn_rcpf(dk);                 \
-        const bool  ng  = dk < 0.0f;                                 \
+        ng              = dk < 0.0f;                                 \
         const float sp  = ng ? -pad : pad;                           \
-        rn              = rd * 0.99999952f;                          \
-        rf              = rd * 1.00000048f;                          \
-        cn              = -((o.c + sp) * rn);                        \
-        cf              = -((o.c - sp) * rf);                        \
-        an              = (row) + (ng ? 16u : 0u);                   \
+        const float r0  = rd * 0.99999952f;                          \
+        const float r1  = rd * 1.00000048f;                          \
+        cn              = (bvh.qmin[k] - (o.c + sp)) * r0;           \
+        cf              = (bvh.qmin[k] - (o.c - sp)) * r1;           \
+        rn              = r0 * bvh.qscale[k];                        \
+        rf              = r1 * bvh.qscale[k];                        \
     }
-    PRT_SLAB_SETUP(x, r.rnx, r.cnx, r.rfx, r.cfx, r.anx, 0u)
-    PRT_SLAB_SETUP(y, r.rny, r.cny, r.rfy, r.cfy, r.any_, 32u)
-    PRT_SLAB_SETUP(z, r.rnz, r.cnz, r.rfz, r.cfz, r.anz, 64u)
+    PRT_SLAB_SETUP(x, 0, r.rnx, r.cnx, r.rfx, r.cfx, r.negx)
+    PRT_SLAB_SETUP(y, 1, r.rny, r.cny, r.rfy, r.cfy, r.negy)
+    PRT_SLAB_SETUP(z, 2, r.rnz, r.cnz, r.rfz, r.cfz, r.negz)
 #undef PRT_SLAB_SETUP
 }
 
@@ -170,10 +179,15 @@ PRT_DEV bool tri_test(const RayCtx& r, float4 q0, float4 q1, float4 q2, float& t
 PRT_DEV int32_t stack_pop(int& sp, const uint32_t* lds, const int32_t* spill)
 {
     --sp;
+    int32_t v;
     if(__builtin_expect(sp < PRT_LDS_STACK, 1))
-        return (int32_t)PRT_STACK_AT(lds, sp);
-    asm volatile("" ::: "memory");  // keep the two loads in their own address spaces (no flat load)
-    return spill[sp - PRT_LDS_STACK];
+        v = (int32_t)PRT_STACK_AT(lds, sp);
+    else
+    {
+        v = spill[sp - PRT_LDS_STACK];
+        asm volatile("" : "+v"(v));  // keeps the two loads apart: ds_read / scratch_load, not one flat load
+    }
+    return v;
 }
 PRT_DEV void stack_push_slow(int& sp, uint32_t* lds, int32_t* spill, int32_t v)
 {
@@ -203,33 +217,37 @@ template <bool ANY>
 PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_t& cur, int& sp, uint32_t* lds,
                         int32_t* spill)
 {
-    const char*    nb   = (const char*)bvh.nodes;
-    const uint32_t base = (uint32_t)cur << 7;
-    const float4   nx   = *(const float4*)(nb + (base + r.anx));
-    const float4   fx   = *(const float4*)(nb + (base + (r.anx ^ 16u)));
-    const float4   ny   = *(const float4*)(nb + (base + r.any_));
-    const float4   fy   = *(const float4*)(nb + (base + (r.any_ ^ 16u)));
-    const float4   nz   = *(const float4*)(nb + (base + r.anz));
-    const float4   fz   = *(const float4*)(nb + (base + (r.anz ^ 16u)));
-    const float4   cq   = *(const float4*)(nb + (base + 96u));
-    const float    inf  = __builtin_inff();
-#define PRT_SLAB(j, key)                                                                                             \
+    const uint4* np = (const uint4*)((const char*)bvh.nodes + ((uint32_t)cur << 6));
+    const uint4  bx = np[0], by = np[1], bz = np[2], cq = np[3];
+    const float  inf = __builtin_inff();
+    // words: .x = min of children 0,1  .y = min of 2,3  .z = max of 0,1  .w = max of 2,3 (16 bits each)
+    const uint32_t nx01 = r.negx ? bx.z : bx.x, nx23 = r.negx ? bx.w : bx.y;
+    const uint32_t fx01 = r.negx ? bx.x : bx.z, fx23 = r.negx ? bx.y : bx.w;
+    const uint32_t ny01 = r.negy ? by.z : by.x, ny23 = r.negy ? by.w : by.y;
+    const uint32_t fy01 = r.negy ? by.x : by.z, fy23 = r.negy ? by.y : by.w;
+    const uint32_t nz01 = r.negz ? bz.z : bz.x, nz23 = r.negz ? bz.w : bz.y;
+    const uint32_t fz01 = r.negz ? bz.x : bz.z, fz23 = r.negz ? bz.y : bz.w;
+#define PRT_QLO(w) ((float)((w) & 0xffffu))
+#define PRT_QHI(w) ((float)((w) >> 16))
+#define PRT_SLAB(Q, nxw, nyw, nzw, fxw, fyw, fzw, key)                                                               \
     {                                                                                                                \
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(nx.j, r.rnx, r.cnx),                        \
-                                                         __builtin_fmaf(ny.j, r.rny, r.cny)),                       \
-                                         __builtin_fmaxf(__builtin_fmaf(nz.j, r.rnz, r.cnz), r.tmin));              \
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(fx.j, r.rfx, r.cfx),                        \
-                                                         __builtin_fmaf(fy.j, r.rfy, r.cfy)),                       \
-                                         __builtin_fminf(__builtin_fmaf(fz.j, r.rfz, r.cfz), tbest));               \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(Q(nxw), r.rnx, r.cnx),                      \
+                                                         __builtin_fmaf(Q(nyw), r.rny, r.cny)),                     \
+                                         __builtin_fmaxf(__builtin_fmaf(Q(nzw), r.rnz, r.cnz), r.tmin));            \
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(Q(fxw), r.rfx, r.cfx),                      \
+                                                         __builtin_fmaf(Q(fyw), r.rfy, r.cfy)),                     \
+                                         __builtin_fminf(__builtin_fmaf(Q(fzw), r.rfz, r.cfz), tbest));             \
         key = (tn <= tf) ? tn : inf;                                                                                 \
     }
     float t0, t1, t2, t3;
-    PRT_SLAB(x, t0)
-    PRT_SLAB(y, t1)
-    PRT_SLAB(z, t2)
-    PRT_SLAB(w, t3)
+    PRT_SLAB(PRT_QLO, nx01, ny01, nz01, fx01, fy01, fz01, t0)
+    PRT_SLAB(PRT_QHI, nx01, ny01, nz01, fx01, fy01, fz01, t1)
+    PRT_SLAB(PRT_QLO, nx23, ny23, nz23, fx23, fy23, fz23, t2)
+    PRT_SLAB(PRT_QHI, nx23, ny23, nz23, fx23, fy23, fz23, t3)
 #undef PRT_SLAB
-    int32_t r0 = __float_as_int(cq.x), r1 = __float_as_int(cq.y), r2 = __float_as_int(cq.z), r3 = __float_as_int(cq.w);
+#undef PRT_QLO
+#undef PRT_QHI
+    int32_t r0 = (int32_t)cq.x, r1 = (int32_t)cq.y, r2 = (int32_t)cq.z, r3 = (int32_t)cq.w;
     if(!ANY)
     {
         PRT_CE(t0, r0, t1, r1)
@@ -266,11 +284,20 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
 {
     const uint32_t ref   = ~(uint32_t)leafRef;
     const uint32_t first = ref >> 3, count = ref & 7u;
-    const float4*  t     = bvh.tris + (size_t)first * 3;
+    if(count == 0) return false;
+    const float4* t = bvh.tris + (size_t)first * 3;
+    float4        a = t[0], b = t[1], c = t[2];
     for(uint32_t i = 0; i < count; ++i)
     {
-        const float4 a = t[3 * i], b = t[3 * i + 1], c = t[3 * i + 2];
-        float        tt, uu, vv;
+        // the next triangle's loads are in flight while this one is tested
+        float4 na = a, nb = b, nc = c;
+        if(i + 1 < count)
+        {
+            na = t[3 * i + 3];
+            nb = t[3 * i + 4];
+            nc = t[3 * i + 5];
+        }
+        float tt, uu, vv;
         if(INSTR) tc.tris++;
         if(tri_test(r, a, b, c, tt, uu, vv))
         {
@@ -289,6 +316,9 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
                 best.prim = p;
             }
         }
+        a = na;
+        b = nb;
+        c = nc;
     }
     return false;
 }
