@@ -78,6 +78,7 @@ typedef struct prt_stats
 #define PRT_K_SHADE 2
 #define PRT_K_SHADOW 3   /* any-hit traversal + accumulate (pathRT.rgen:818-822, 939-942) */
 #define PRT_K_AO_SHADE 4 /* AO.rgen:222-272 */
+#define PRT_K_RESOLVE 5  /* E += terms of the pass, in path order (pathRT.rgen:939-942, :973) */
 #define PRT_K_COUNT 8
 
 typedef struct prt_profile
@@ -122,6 +123,10 @@ int prt_render_iteration(prt_context* ctx, int mode);
  * overwritten for each. stride > 1 is the multi-GPU sample sharding (rank r renders first_iter = 1+r,
  * stride = world size). */
 int prt_render(prt_context* ctx, int mode, uint32_t first_iter, uint32_t n_iter, uint32_t iter_stride);
+/* Iterations of the path mode are independent until their radiance terms are added to the image, so up to
+ * `n` of them (1..8, default 4) are in flight on separate HIP streams; the sums are still formed in iteration
+ * order (bit-identical to n = 1). No counterpart in the reference (one queue, one frame at a time). */
+int prt_set_pipeline_depth(prt_context* ctx, int n);
 /* vkQueueWaitIdle — vkTools.cpp:212 */
 int prt_sync(prt_context* ctx);
 

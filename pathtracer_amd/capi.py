@@ -22,12 +22,12 @@ EXPORTS = [
     "prt_upload_scrambles", "prt_set_uniforms", "prt_set_flags", "prt_render_iteration", "prt_render", "prt_sync",
     "prt_clear_accum", "prt_read_accum", "prt_device_accum_ptr", "prt_bind_accum", "prt_postprocess",
     "prt_read_hit_ids", "prt_get_stats", "prt_reset_stats", "prt_trace", "prt_trace_device", "prt_read_bvh",
-    "prt_read_sobol", "prt_set_profiling", "prt_get_profile",
+    "prt_read_sobol", "prt_set_profiling", "prt_get_profile", "prt_set_pipeline_depth",
 ]
 
-K_GENERATE, K_EXTEND, K_SHADE, K_SHADOW, K_AO_SHADE, K_COUNT = 0, 1, 2, 3, 4, 8
+K_GENERATE, K_EXTEND, K_SHADE, K_SHADOW, K_AO_SHADE, K_RESOLVE, K_COUNT = 0, 1, 2, 3, 4, 5, 8
 KERNEL_NAMES = {K_GENERATE: "generate", K_EXTEND: "extend", K_SHADE: "shade", K_SHADOW: "shadow",
-                K_AO_SHADE: "ao_shade"}
+                K_AO_SHADE: "ao_shade", K_RESOLVE: "resolve"}
 
 
 class Stats(C.Structure):
@@ -87,6 +87,7 @@ def lib():
         L.prt_read_sobol.argtypes = [vp, vp]
         L.prt_set_profiling.argtypes = [vp, i32]
         L.prt_get_profile.argtypes = [vp, C.POINTER(Profile)]
+        L.prt_set_pipeline_depth.argtypes = [vp, i32]
         for name in EXPORTS:
             if name != "prt_last_error":
                 getattr(L, name).restype = i32
@@ -174,6 +175,9 @@ class Context:
 
     def sync(self):
         self._chk(self.L.prt_sync(self.h_))
+
+    def set_pipeline_depth(self, n):
+        self._chk(self.L.prt_set_pipeline_depth(self.h_, n))
 
     def clear_accum(self):
         self._chk(self.L.prt_clear_accum(self.h_))

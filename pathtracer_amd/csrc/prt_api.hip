@@ -20,10 +20,31 @@ using namespace prt;
 
 static std::string g_createError;
 
+static constexpr uint32_t kStatWords    = 8;
+static constexpr uint32_t kCounterWords = 256;
+static constexpr uint32_t kMaxBounces   = 24;  // UI cap is 10 (vkContext.cpp:266)
+static constexpr int      kMaxPipes     = 8;
+
+// Per-pass state: one iteration (pass) is in flight per pipe, each on its own HIP stream.
+struct Pipe
+{
+    hipStream_t stream = nullptr;
+    float4 *    rayO = nullptr, *rayD = nullptr, *hit = nullptr, *thr = nullptr, *shO = nullptr, *shD = nullptr,
+           *eiVis = nullptr, *contrib = nullptr;
+    float2*    aaOff  = nullptr;
+    uint32_t*  hitIds = nullptr;
+    uint8_t *  dead = nullptr, *nvert = nullptr;
+    uint32_t * q[2] = {nullptr, nullptr}, *qShadow = nullptr;
+    uint32_t*  counters   = nullptr;  // kCounterWords per pass
+    uint32_t   contribCap = 0;        // path vertices the contrib buffer holds
+    hipEvent_t evDone = nullptr, evFree = nullptr;
+    bool       allocated = false, busy = false;  // busy: a resolve that frees the pipe has been enqueued
+};
+
 struct prt_context
 {
     int         device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // accumulation order: k_resolve of every pass, scene upload, BVH build, read-backs
     uint32_t    w = 0, h = 0, npix = 0;
     uint32_t    flags = 0, seed = 1;
     int         numCU = 256;
@@ -54,20 +75,16 @@ struct prt_context
     uint32_t* dScramble = nullptr;
 
     // frame
-    prt_uniforms  ubo{};
-    prt_uniforms* dUbo = nullptr;  // ring of device copies, one per in-flight iteration
-    prt_uniforms* hUbo = nullptr;  // pinned staging ring
-    uint32_t      uboSlot = 0;
-    float4 *      accumOwn = nullptr, *accum = nullptr;
-    float4 *      rayO = nullptr, *rayD = nullptr, *hit = nullptr, *thr = nullptr, *shO = nullptr, *shD = nullptr,
-           *eiVis = nullptr, *eiOcc = nullptr;
-    float2*             aaOff  = nullptr;
-    uint32_t*           hitIds = nullptr;
-    uint8_t*            dead   = nullptr;
-    uint32_t *          q[2] = {nullptr, nullptr}, *qShadow = nullptr;
-    uint32_t*           counters = nullptr;  // kCounterWords per pass
-    unsigned long long* stats    = nullptr;
-    uint64_t            iterations = 0;
+    prt_uniforms        ubo{};
+    float4 *            accumOwn = nullptr, *accum = nullptr;
+    Pipe                pipes[kMaxPipes];
+    int                 nPipes   = 4;   // passes in flight (prt_set_pipeline_depth)
+    int                 nextPipe = 0, lastPipe = 0;
+    int                 lastMode = -1;
+    bool                lastPipelined = false;
+    uint32_t*           batchCounter = nullptr;
+    unsigned long long* stats        = nullptr;
+    uint64_t            iterations   = 0;
 
     // profiling
     int profLevel = 0;
@@ -81,12 +98,6 @@ struct prt_context
     double                  profMs[PRT_K_COUNT]       = {};
     uint64_t                profLaunches[PRT_K_COUNT] = {};
 };
-
-static constexpr uint32_t kStatWords = 8;
-
-static constexpr uint32_t kUboRing      = 64;
-static constexpr uint32_t kCounterWords = 256;
-static constexpr uint32_t kMaxBounces   = 24;  // UI cap is 10 (vkContext.cpp:266)
 
 static int fail(prt_context* c, int code, const char* fmt, ...)
 {
@@ -122,6 +133,62 @@ static void dfree(T*& p)
     p = nullptr;
 }
 static inline uint32_t cdiv(size_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+static void pipe_free(Pipe& p)
+{
+    dfree(p.rayO); dfree(p.rayD); dfree(p.hit); dfree(p.thr); dfree(p.shO); dfree(p.shD); dfree(p.eiVis);
+    dfree(p.contrib); dfree(p.aaOff); dfree(p.hitIds); dfree(p.dead); dfree(p.nvert); dfree(p.q[0]); dfree(p.q[1]);
+    dfree(p.qShadow); dfree(p.counters);
+    if(p.evDone) (void)hipEventDestroy(p.evDone);
+    if(p.evFree) (void)hipEventDestroy(p.evFree);
+    if(p.stream) (void)hipStreamDestroy(p.stream);
+    p = Pipe();
+}
+static hipError_t pipe_alloc(Pipe& p, size_t n)
+{
+    if(p.allocated) return hipSuccess;
+    hipError_t e = hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking);
+    if(e == hipSuccess) e = hipEventCreateWithFlags(&p.evDone, hipEventDisableTiming);
+    if(e == hipSuccess) e = hipEventCreateWithFlags(&p.evFree, hipEventDisableTiming);
+    if(e == hipSuccess) e = dalloc(p.rayO, n);
+    if(e == hipSuccess) e = dalloc(p.rayD, n);
+    if(e == hipSuccess) e = dalloc(p.hit, n);
+    if(e == hipSuccess) e = dalloc(p.thr, n);
+    if(e == hipSuccess) e = dalloc(p.shO, n);
+    if(e == hipSuccess) e = dalloc(p.shD, n);
+    if(e == hipSuccess) e = dalloc(p.eiVis, n);
+    if(e == hipSuccess) e = dalloc(p.aaOff, n);
+    if(e == hipSuccess) e = dalloc(p.hitIds, n);
+    if(e == hipSuccess) e = dalloc(p.dead, n);
+    if(e == hipSuccess) e = dalloc(p.nvert, n);
+    if(e == hipSuccess) e = dalloc(p.q[0], n);
+    if(e == hipSuccess) e = dalloc(p.q[1], n);
+    if(e == hipSuccess) e = dalloc(p.qShadow, n);
+    if(e == hipSuccess) e = dalloc(p.counters, (size_t)kCounterWords);
+    if(e == hipSuccess) e = hipMemset(p.dead, 0, n);
+    if(e == hipSuccess) e = hipMemset(p.nvert, 0, n);
+    if(e == hipSuccess) e = hipMemset(p.hitIds, 0xff, n * 4);
+    if(e == hipSuccess) p.allocated = true;
+    return e;
+}
+// every stream of the context idle
+static hipError_t sync_all(prt_context* c)
+{
+    hipError_t e = hipSuccess;
+    for(Pipe& p : c->pipes)
+        if(p.stream)
+        {
+            const hipError_t e2 = hipStreamSynchronize(p.stream);
+            if(e == hipSuccess) e = e2;
+            p.busy = false;
+        }
+    if(c->stream)
+    {
+        const hipError_t e2 = hipStreamSynchronize(c->stream);
+        if(e == hipSuccess) e = e2;
+    }
+    return e;
+}
 
 static void prof_collect(prt_context* c);
 
@@ -203,24 +270,9 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
     }
     const size_t n = c->npix;
     if(e == hipSuccess) e = dalloc(c->accumOwn, n);
-    if(e == hipSuccess) e = dalloc(c->rayO, n);
-    if(e == hipSuccess) e = dalloc(c->rayD, n);
-    if(e == hipSuccess) e = dalloc(c->hit, n);
-    if(e == hipSuccess) e = dalloc(c->thr, n);
-    if(e == hipSuccess) e = dalloc(c->shO, n);
-    if(e == hipSuccess) e = dalloc(c->shD, n);
-    if(e == hipSuccess) e = dalloc(c->eiVis, n);
-    if(e == hipSuccess) e = dalloc(c->eiOcc, n);
-    if(e == hipSuccess) e = dalloc(c->aaOff, n);
-    if(e == hipSuccess) e = dalloc(c->hitIds, n);
-    if(e == hipSuccess) e = dalloc(c->dead, n);
-    if(e == hipSuccess) e = dalloc(c->q[0], n);
-    if(e == hipSuccess) e = dalloc(c->q[1], n);
-    if(e == hipSuccess) e = dalloc(c->qShadow, n);
-    if(e == hipSuccess) e = dalloc(c->counters, (size_t)kCounterWords);
+    if(e == hipSuccess) e = pipe_alloc(c->pipes[0], n);
+    if(e == hipSuccess) e = dalloc(c->batchCounter, (size_t)4);
     if(e == hipSuccess) e = dalloc(c->stats, (size_t)kStatWords);
-    if(e == hipSuccess) e = dalloc(c->dUbo, (size_t)kUboRing);
-    if(e == hipSuccess) e = hipHostMalloc((void**)&c->hUbo, kUboRing * sizeof(prt_uniforms), hipHostMallocDefault);
     if(e == hipSuccess) e = dalloc(c->dSobol, (size_t)64 * 32);
     if(e == hipSuccess)
     {
@@ -230,8 +282,11 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
     }
     if(e == hipSuccess) e = hipMemset(c->accumOwn, 0, n * sizeof(float4));
     if(e == hipSuccess) e = hipMemset(c->stats, 0, kStatWords * sizeof(unsigned long long));
-    if(e == hipSuccess) e = hipMemset(c->dead, 0, n);
-    if(e == hipSuccess) e = hipMemset(c->hitIds, 0xff, n * 4);
+    if(const char* pe = getenv("PRT_PIPES"))
+    {
+        const int np = atoi(pe);
+        if(np >= 1 && np <= kMaxPipes) c->nPipes = np;
+    }
     if(e != hipSuccess)
     {
         fail(nullptr, PRT_E_HIP, "prt_create: %s", hipGetErrorString(e));
@@ -255,31 +310,16 @@ int prt_destroy(prt_context* c)
 {
     if(!c) return PRT_OK;
     (void)hipSetDevice(c->device);
-    if(c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     free_scene(c);
     dfree(c->accumOwn);
-    dfree(c->rayO);
-    dfree(c->rayD);
-    dfree(c->hit);
-    dfree(c->thr);
-    dfree(c->shO);
-    dfree(c->shD);
-    dfree(c->eiVis);
-    dfree(c->eiOcc);
-    dfree(c->aaOff);
-    dfree(c->hitIds);
-    dfree(c->dead);
-    dfree(c->q[0]);
-    dfree(c->q[1]);
-    dfree(c->qShadow);
-    dfree(c->counters);
+    dfree(c->batchCounter);
     dfree(c->stats);
-    dfree(c->dUbo);
-    if(c->hUbo) (void)hipHostFree(c->hUbo);
     dfree(c->dSobol);
     dfree(c->dScramble);
     prof_collect(c);
     for(hipEvent_t e : c->eventPool) (void)hipEventDestroy(e);
+    for(Pipe& p : c->pipes) pipe_free(p);
     if(c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PRT_OK;
@@ -295,7 +335,7 @@ int prt_set_scene(prt_context* c, const prt_vertex* v, size_t nv, const uint32_t
     for(size_t i = 0; i < (nidx / 3) * 3; ++i)
         if(idx[i] >= nv) return fail(c, PRT_E_INVALID, "prt_set_scene: index %zu (= %u) out of range", i, idx[i]);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     free_scene(c);
     c->nverts = (uint32_t)nv;
     c->ntri   = (uint32_t)(nidx / 3);
@@ -342,7 +382,7 @@ int prt_build_accel(prt_context* c)
     if(!c) return PRT_E_INVALID;
     if(!c->haveScene) return fail(c, PRT_E_NOSCENE, "prt_build_accel: no scene");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     const auto     t0 = std::chrono::steady_clock::now();
     const uint32_t N  = c->ntri;
     hipStream_t    st = c->stream;
@@ -490,7 +530,7 @@ int prt_set_scramble_seed(prt_context* c, uint32_t seed)
 {
     if(!c) return PRT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     dfree(c->dScramble);
     c->seed = seed;
     return PRT_OK;
@@ -501,7 +541,7 @@ int prt_upload_scrambles(prt_context* c, const uint32_t* layers, uint32_t nlayer
     if(!c) return PRT_E_INVALID;
     if(!layers || nlayers != 32) return fail(c, PRT_E_INVALID, "prt_upload_scrambles: need 32 layers");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     dfree(c->dScramble);
     HIPCHK(c, dalloc(c->dScramble, (size_t)32 * c->npix));
     HIPCHK(c, hipMemcpy(c->dScramble, layers, (size_t)32 * c->npix * 4, hipMemcpyHostToDevice));
@@ -542,7 +582,7 @@ static hipEvent_t prof_event(prt_context* c)
 static void prof_collect(prt_context* c)
 {
     if(c->pending.empty()) return;
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     for(auto& p : c->pending)
     {
         float ms = 0.0f;
@@ -561,13 +601,14 @@ struct ProfScope
 {
     prt_context* c;
     int          kind;
+    hipStream_t  st;
     hipEvent_t   e0 = nullptr;
-    ProfScope(prt_context* c_, int k) : c(c_), kind(k)
+    ProfScope(prt_context* c_, int k, hipStream_t s_) : c(c_), kind(k), st(s_)
     {
         if(c->profLevel > 0)
         {
             e0 = prof_event(c);
-            (void)hipEventRecord(e0, c->stream);
+            (void)hipEventRecord(e0, st);
         }
     }
     ~ProfScope()
@@ -575,13 +616,13 @@ struct ProfScope
         if(e0)
         {
             hipEvent_t e1 = prof_event(c);
-            (void)hipEventRecord(e1, c->stream);
+            (void)hipEventRecord(e1, st);
             c->pending.push_back({kind, e0, e1});
         }
     }
 };
 
-static void make_views(prt_context* c, SceneView& sc, FrameView& f)
+static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& f)
 {
     sc.verts        = c->dVerts;
     sc.idx          = c->dIdx;
@@ -602,113 +643,132 @@ static void make_views(prt_context* c, SceneView& sc, FrameView& f)
         sc.bvh.qmin[k]   = c->grid.qmin[k];
         sc.bvh.qscale[k] = c->grid.qscale[k];
     }
-    f.w             = c->w;
-    f.h             = c->h;
-    f.npix          = c->npix;
-    f.accum         = c->accum;
-    f.rayO          = c->rayO;
-    f.rayD          = c->rayD;
-    f.hit           = c->hit;
-    f.thr           = c->thr;
-    f.shO           = c->shO;
-    f.shD           = c->shD;
-    f.eiVis         = c->eiVis;
-    f.eiOcc         = c->eiOcc;
-    f.aaOff         = c->aaOff;
-    f.hitIds        = c->hitIds;
-    f.dead          = c->dead;
-    f.stats         = c->stats;
+    f.w       = c->w;
+    f.h       = c->h;
+    f.npix    = c->npix;
+    f.accum   = c->accum;
+    f.rayO    = p.rayO;
+    f.rayD    = p.rayD;
+    f.hit     = p.hit;
+    f.thr     = p.thr;
+    f.shO     = p.shO;
+    f.shD     = p.shD;
+    f.eiVis   = p.eiVis;
+    f.contrib = p.contrib;
+    f.aaOff   = p.aaOff;
+    f.hitIds  = p.hitIds;
+    f.dead    = p.dead;
+    f.nvert   = p.nvert;
+    f.stats   = c->stats;
 }
 
-static void launch_extend(prt_context* c, const SceneView& sc, const FrameView& f, uint32_t grid, const uint32_t* q,
-                          const uint32_t* n, uint32_t* work, uint32_t primary)
+static void launch_extend(prt_context* c, hipStream_t st, const SceneView& sc, const FrameView& f, uint32_t grid,
+                          const uint32_t* q, const uint32_t* n, uint32_t* work, uint32_t primary)
 {
-    ProfScope ps(c, PRT_K_EXTEND);
+    ProfScope ps(c, PRT_K_EXTEND, st);
     if(c->profLevel >= 2)
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc, f, q, n, work, primary,
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, q, n, work, primary,
                            trace_tune());
     else
-        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc, f, q, n, work,
-                           primary, trace_tune());
+        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, q, n, work, primary,
+                           trace_tune());
 }
 
-// One vkCmdTraceRaysNV(W,H,1): a fixed launch sequence, no host synchronisation.
-static int render_one(prt_context* c, int mode)
+// AO.rgen: generate -> extend -> AO rays + accumulate, on the context's main stream with pipe 0's buffers.
+static int render_ao(prt_context* c)
 {
+    Pipe&       p  = c->pipes[0];
     hipStream_t st = c->stream;
     SceneView   sc;
     FrameView   f;
-    make_views(c, sc, f);
-    // parameters for this iteration: the ring slot is reused only after kUboRing iterations
-    if(c->uboSlot == kUboRing)
+    make_views(c, p, sc, f);
+    const uint32_t gridPix = cdiv(c->npix, 256);
+    HIPCHK(c, hipMemsetAsync(p.counters, 0, kCounterWords * 4, st));
     {
-        HIPCHK(c, hipStreamSynchronize(st));
-        c->uboSlot = 0;
+        ProfScope ps(c, PRT_K_GENERATE, st);
+        hipLaunchKernelGGL(k_ao_generate, dim3(gridPix), dim3(256), 0, st, f, c->ubo, c->flags);
     }
-    prt_uniforms* dU = c->dUbo + c->uboSlot;
-    prt_uniforms* hU = c->hUbo + c->uboSlot;
-    c->uboSlot++;
-    *hU = c->ubo;
-    HIPCHK(c, hipMemcpyAsync(dU, hU, sizeof(prt_uniforms), hipMemcpyHostToDevice, st));
-    const uint32_t gridPix   = cdiv(c->npix, 256);
-    const uint32_t gridShade = (uint32_t)c->numCU * 8u;
-    if(mode == PRT_MODE_AO)
+    launch_extend(c, st, sc, f, c->gridExtend, nullptr, nullptr, p.counters + 0, 1u);
     {
-        HIPCHK(c, hipMemsetAsync(c->counters, 0, kCounterWords * 4, st));
-        {
-            ProfScope ps(c, PRT_K_GENERATE);
-            hipLaunchKernelGGL(k_ao_generate, dim3(gridPix), dim3(256), 0, st, f, (const prt_uniforms*)dU, c->flags);
-        }
-        launch_extend(c, sc, f, c->gridExtend, nullptr, nullptr, c->counters + 0, 1u);
-        {
-            ProfScope ps(c, PRT_K_AO_SHADE);
-            hipLaunchKernelGGL(k_ao_shade, dim3(c->gridAo), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                               (const prt_uniforms*)dU, c->flags, c->counters + 1);
-        }
-        HIPCHK(c, hipGetLastError());
-        c->iterations++;
-        return PRT_OK;
+        ProfScope ps(c, PRT_K_AO_SHADE, st);
+        hipLaunchKernelGGL(k_ao_shade, dim3(c->gridAo), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo, c->flags,
+                           p.counters + 1);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->lastPipe = 0;
+    return PRT_OK;
+}
+
+// One pass of pathRT.rgen (one aaRay of one vkCmdTraceRaysNV(W,H,1)): a fixed launch sequence on the pipe's
+// stream, then k_resolve on the main stream (iteration order). No host synchronisation.
+static int render_path_pass(prt_context* c, int pi, int aa)
+{
+    Pipe& p = c->pipes[pi];
+    if(!p.allocated)
+    {
+        const hipError_t e = pipe_alloc(p, c->npix);
+        if(e != hipSuccess) return fail(c, PRT_E_HIP, "pipe allocation failed: %s", hipGetErrorString(e));
     }
     const int B = c->ubo.numIndirectBounces;
-    for(int aa = 0; aa < c->ubo.numAArays; ++aa)
+    if(p.contribCap < (uint32_t)B + 1u)
     {
-        // counters: [0..31] path-queue lengths per bounce, [32..63] shadow-queue lengths,
-        //           [64..127] work-fetch cursors of the extend launches, [128..191] of the shadow launches
-        HIPCHK(c, hipMemsetAsync(c->counters, 0, kCounterWords * 4, st));
-        const uint32_t fl = c->flags | ((uint32_t)aa << 8);
-        {
-            ProfScope ps(c, PRT_K_GENERATE);
-            hipLaunchKernelGGL(k_generate, dim3(gridPix), dim3(256), 0, st, sc, f, (const prt_uniforms*)dU, c->flags,
-                               (uint32_t)aa);
-        }
-        for(int b = 0; b <= B; ++b)
-        {
-            const uint32_t* qIn  = b == 0 ? nullptr : c->q[b & 1];
-            const uint32_t* nIn  = b == 0 ? nullptr : c->counters + b;
-            uint32_t*       qOut = c->q[(b + 1) & 1];
-            launch_extend(c, sc, f, c->gridExtend, qIn, nIn, c->counters + 64 + b, b == 0 ? 1u : 0u);
-            {
-                ProfScope ps(c, PRT_K_SHADE);
-                hipLaunchKernelGGL(k_shade, dim3(gridShade), dim3(256), 0, st, sc, f, (const prt_uniforms*)dU, fl,
-                                   (uint32_t)b, qIn, nIn, qOut, c->counters + b + 1, c->qShadow,
-                                   c->counters + 32 + b);
-            }
-            {
-                ProfScope ps(c, PRT_K_SHADOW);
-                if(c->profLevel >= 2)
-                    hipLaunchKernelGGL(k_shadow<true>, dim3(c->gridShadow), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                                       (const uint32_t*)c->qShadow, (const uint32_t*)(c->counters + 32 + b),
-                                       c->counters + 128 + b, trace_tune());
-                else
-                    hipLaunchKernelGGL(k_shadow<false>, dim3(c->gridShadow), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                                       (const uint32_t*)c->qShadow, (const uint32_t*)(c->counters + 32 + b),
-                                       c->counters + 128 + b, trace_tune());
-            }
-            if(c->pending.size() > 8192) prof_collect(c);
-        }
-        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, sync_all(c));
+        dfree(p.contrib);
+        p.contribCap = 0;
+        HIPCHK(c, dalloc(p.contrib, (size_t)(B + 1) * c->npix));
+        p.contribCap = (uint32_t)B + 1u;
     }
-    c->iterations++;
+    hipStream_t st = p.stream;
+    SceneView   sc;
+    FrameView   f;
+    make_views(c, p, sc, f);
+    if(p.busy) HIPCHK(c, hipStreamWaitEvent(st, p.evFree, 0));  // the terms of its previous pass have been summed
+    const uint32_t gridPix   = cdiv(c->npix, 256);
+    const uint32_t gridShade = (uint32_t)c->numCU * 8u;
+    // counters: [0..31] path-queue lengths per bounce, [32..63] shadow-queue lengths,
+    //           [64..127] work-fetch cursors of the extend launches, [128..191] of the shadow launches
+    HIPCHK(c, hipMemsetAsync(p.counters, 0, kCounterWords * 4, st));
+    const uint32_t fl = c->flags | ((uint32_t)aa << 8);
+    {
+        ProfScope ps(c, PRT_K_GENERATE, st);
+        hipLaunchKernelGGL(k_generate, dim3(gridPix), dim3(256), 0, st, sc, f, c->ubo, c->flags, (uint32_t)aa);
+    }
+    for(int b = 0; b <= B; ++b)
+    {
+        const uint32_t* qIn  = b == 0 ? nullptr : p.q[b & 1];
+        const uint32_t* nIn  = b == 0 ? nullptr : p.counters + b;
+        uint32_t*       qOut = p.q[(b + 1) & 1];
+        launch_extend(c, st, sc, f, c->gridExtend, qIn, nIn, p.counters + 64 + b, b == 0 ? 1u : 0u);
+        {
+            ProfScope ps(c, PRT_K_SHADE, st);
+            hipLaunchKernelGGL(k_shade, dim3(gridShade), dim3(256), 0, st, sc, f, c->ubo, fl, (uint32_t)b, qIn, nIn,
+                               qOut, p.counters + b + 1, p.qShadow, p.counters + 32 + b);
+        }
+        {
+            ProfScope ps(c, PRT_K_SHADOW, st);
+            if(c->profLevel >= 2)
+                hipLaunchKernelGGL(k_shadow<true>, dim3(c->gridShadow), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+                                   (const uint32_t*)p.qShadow, (const uint32_t*)(p.counters + 32 + b),
+                                   p.counters + 128 + b, (uint32_t)b, trace_tune());
+            else
+                hipLaunchKernelGGL(k_shadow<false>, dim3(c->gridShadow), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+                                   (const uint32_t*)p.qShadow, (const uint32_t*)(p.counters + 32 + b),
+                                   p.counters + 128 + b, (uint32_t)b, trace_tune());
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(p.evDone, st));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, p.evDone, 0));
+    {
+        ProfScope ps(c, PRT_K_RESOLVE, c->stream);
+        hipLaunchKernelGGL(k_resolve, dim3(gridPix), dim3(256), 0, c->stream, c->accum, (const float4*)p.contrib,
+                           (const uint8_t*)p.nvert, c->npix);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(p.evFree, c->stream));
+    p.busy      = true;
+    c->lastPipe = pi;
+    if(c->pending.size() > 8192) prof_collect(c);
     return PRT_OK;
 }
 
@@ -718,7 +778,30 @@ int prt_render_iteration(prt_context* c, int mode)
     if(mode != PRT_MODE_PATH && mode != PRT_MODE_AO) return fail(c, PRT_E_INVALID, "prt_render_iteration: mode %d", mode);
     if(!c->haveAccel) return fail(c, PRT_E_NOSCENE, "prt_render_iteration: no acceleration structure");
     HIPCHK(c, hipSetDevice(c->device));
-    return render_one(c, mode);
+    if(mode != c->lastMode)
+    {
+        HIPCHK(c, sync_all(c));  // AO works on pipe 0's buffers from the main stream
+        c->lastMode = mode;
+    }
+    int rc = PRT_OK;
+    if(mode == PRT_MODE_AO)
+        rc = render_ao(c);
+    else
+    {
+        // Passes are independent up to k_resolve, so consecutive iterations run on different pipes. The aaRays of
+        // one iteration depend on each other through `dead` (a primary miss ends the pixel's iteration), and the
+        // literal image semantics are defined pass after pass: both stay on pipe 0.
+        const bool pipelined = c->nPipes > 1 && c->ubo.numAArays == 1 && !(c->flags & PRT_FLAG_LITERAL);
+        if(pipelined)
+        {
+            rc          = render_path_pass(c, c->nextPipe, 0);
+            c->nextPipe = (c->nextPipe + 1) % c->nPipes;
+        }
+        else
+            for(int aa = 0; aa < c->ubo.numAArays && rc == PRT_OK; ++aa) rc = render_path_pass(c, 0, aa);
+    }
+    if(rc == PRT_OK) c->iterations++;
+    return rc;
 }
 
 int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t stride)
@@ -734,11 +817,22 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
     return PRT_OK;
 }
 
+int prt_set_pipeline_depth(prt_context* c, int n)
+{
+    if(!c) return PRT_E_INVALID;
+    if(n < 1 || n > kMaxPipes) return fail(c, PRT_E_LIMIT, "prt_set_pipeline_depth: %d outside [1,%d]", n, kMaxPipes);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, sync_all(c));
+    c->nPipes   = n;
+    c->nextPipe = 0;
+    return PRT_OK;
+}
+
 int prt_sync(prt_context* c)
 {
     if(!c) return PRT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     return PRT_OK;
 }
 
@@ -771,7 +865,7 @@ int prt_bind_accum(prt_context* c, void* p)
     if(!c) return PRT_E_INVALID;
     if(((uintptr_t)p & 15u) != 0) return fail(c, PRT_E_INVALID, "prt_bind_accum: pointer not 16-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     c->accum = p ? (float4*)p : c->accumOwn;
     return PRT_OK;
 }
@@ -795,8 +889,8 @@ int prt_read_hit_ids(prt_context* c, uint32_t* out)
 {
     if(!c || !out) return PRT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(out, c->hitIds, (size_t)c->npix * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
+    HIPCHK(c, hipMemcpy(out, c->pipes[c->lastPipe].hitIds, (size_t)c->npix * 4, hipMemcpyDeviceToHost));
     return PRT_OK;
 }
 
@@ -805,8 +899,8 @@ int prt_get_stats(prt_context* c, prt_stats* s)
     if(!c || !s) return PRT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     unsigned long long rays[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(rays, c->stats, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
+    HIPCHK(c, hipMemcpy(rays, c->stats, 16, hipMemcpyDeviceToHost));
     s->rays            = rays[0] + rays[1];
     s->iterations      = c->iterations;
     s->bvh_nodes       = c->nNodes;
@@ -821,7 +915,8 @@ int prt_reset_stats(prt_context* c)
     if(!c) return PRT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     prof_collect(c);
-    HIPCHK(c, hipMemsetAsync(c->stats, 0, kStatWords * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, sync_all(c));
+    HIPCHK(c, hipMemset(c->stats, 0, kStatWords * sizeof(unsigned long long)));
     c->iterations = 0;
     for(int k = 0; k < PRT_K_COUNT; ++k)
     {
@@ -846,8 +941,8 @@ int prt_get_profile(prt_context* c, prt_profile* out)
     HIPCHK(c, hipSetDevice(c->device));
     prof_collect(c);
     unsigned long long st[kStatWords];
-    HIPCHK(c, hipMemcpyAsync(st, c->stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
+    HIPCHK(c, hipMemcpy(st, c->stats, sizeof st, hipMemcpyDeviceToHost));
     for(int k = 0; k < PRT_K_COUNT; ++k)
     {
         out->ms[k]       = c->profMs[k];
@@ -871,12 +966,11 @@ int prt_trace_device(prt_context* c, const void* rays, size_t n, int any, void* 
     if(n == 0) { if(ms) *ms = 0.0f; return PRT_OK; }
     SceneView sc;
     FrameView f;
-    make_views(c, sc, f);
+    make_views(c, c->pipes[0], sc, f);
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
-    // counters[192]: work-fetch cursor of this launch (the render passes use words 0..191)
-    uint32_t*      work = c->counters + 192;
+    uint32_t*      work = c->batchCounter;  // work-fetch cursor of this launch
     const uint32_t grid = c->gridBatch;
     HIPCHK(c, hipMemsetAsync(work, 0, 4, c->stream));
     HIPCHK(c, hipEventRecord(e0, c->stream));

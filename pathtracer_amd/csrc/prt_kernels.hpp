@@ -11,7 +11,12 @@
 //   shade     : vertex/material fetch, textures, bump, light sample, GGX VNDF sample, termination;
 //               emits the shadow ray + both possible radiance terms and the next ray;
 //               surviving paths are compacted into the next queue with wave ballots  (:699-961)
-//   shadow    : any-hit traversal, then E += (visible ? Ei_vis : Ei_occ, color.w)   (:818-847,:939-942)
+//   shadow    : any-hit traversal; the vertex's radiance term becomes Ei_vis when the light sample is
+//               visible (it was stored as Ei_occ by shade)                            (:818-847)
+//   resolve   : E += term[0] + term[1] + ... in path order, once per pass             (:939-942)
+//
+// Passes (iterations) are independent until `resolve`, so several of them are in flight on separate
+// HIP streams (prt_api.hip); `resolve` runs in iteration order, which keeps the fp32 sums bit-exact.
 //
 // All per-path state is pixel-indexed SoA (float4 records -> 16-byte coalesced accesses); queues
 // hold pixel ids. Queue lengths live in device memory, kernels are persistent (wave-granular work
@@ -46,11 +51,12 @@ struct FrameView
     float4*   thr;    // throughput.xyz, p
     float4*   shO;    // hitPoint.xyz, color.w
     float4*   shD;    // vLight.xyz, -
-    float4*   eiVis;  // radiance term if the light sample is visible
-    float4*   eiOcc;  // radiance term if it is occluded
+    float4*   eiVis;  // radiance term if the light sample is visible (w = color.w)
+    float4*   contrib;  // [vertex][npix]: radiance term of every path vertex of this pass (w = color.w)
     float2*   aaOff;  // rayOffset (only read when numAArays != 1)
     uint32_t* hitIds; // primary-ray primitive id per pixel
-    uint8_t*  dead;   // literal mode: pixel returned early in this iteration (primary miss)
+    uint8_t*  dead;   // pixel returned early in this iteration (primary miss)
+    uint8_t*  nvert;  // terms stored for the pixel in this pass | 0x40 overwrite E | 0x80 reset E first
     unsigned long long* stats;  // [0] closest-hit rays, [1] any-hit rays, [2..3] nodes / triangles visited by
                                 // closest-hit rays, [4..5] by any-hit rays (profiling level 2 only)
 };
@@ -108,15 +114,16 @@ PRT_DEV void flush_counts(const FrameView& f, uint32_t rays, TraceCount tc, int 
 // ---------------------------------------------------------------------------------------------
 // generate — pathRT.rgen:624-690
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_generate(SceneView sc, FrameView f, const prt_uniforms* __restrict__ ubo,
-                                                  uint32_t flags, uint32_t aa)
+__global__ void __launch_bounds__(256) k_generate(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,
+                                                  uint32_t aa)
 {
-    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x;
+    const prt_uniforms* ubo = &ubo_;
+    const uint32_t      px  = blockIdx.x * blockDim.x + threadIdx.x;
     if(px >= f.npix) return;
     const bool literal = (flags & PRT_FLAG_LITERAL) != 0;
+    f.nvert[px] = (aa == 0 && literal && !(ubo->iteration > 1u)) ? 0x80 : 0;  // pathRT.rgen:649-654
     if(aa == 0)
     {
-        if(literal && !(ubo->iteration > 1u)) f.accum[px] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         f.dead[px] = 0;
     }
     else if(f.dead[px])
@@ -152,9 +159,10 @@ __global__ void __launch_bounds__(256) k_generate(SceneView sc, FrameView f, con
 }
 
 // AO.rgen:185-205 — pixel-centre primary ray, tmin 1e-5
-__global__ void __launch_bounds__(256) k_ao_generate(FrameView f, const prt_uniforms* __restrict__ ubo, uint32_t flags)
+__global__ void __launch_bounds__(256) k_ao_generate(FrameView f, const prt_uniforms ubo_, uint32_t flags)
 {
-    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x;
+    const prt_uniforms* ubo = &ubo_;
+    const uint32_t      px  = blockIdx.x * blockDim.x + threadIdx.x;
     if(px >= f.npix) return;
     if((flags & PRT_FLAG_LITERAL) && !(ubo->iteration > 1u)) f.accum[px] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     f3 Ro, Rd;
@@ -225,12 +233,13 @@ PRT_DEV VertexU load_vertex(const prt_vertex* __restrict__ verts, uint32_t index
     return v;
 }
 
-__global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const prt_uniforms* __restrict__ ubo,
-                                               uint32_t flags, uint32_t bounce, const uint32_t* __restrict__ queueIn,
+__global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,
+                                               uint32_t bounce, const uint32_t* __restrict__ queueIn,
                                                const uint32_t* __restrict__ countIn, uint32_t* __restrict__ queueNext,
                                                uint32_t* countNext, uint32_t* __restrict__ queueShadow,
                                                uint32_t* countShadow)
 {
+    const prt_uniforms* ubo = &ubo_;
     const uint32_t count      = countIn ? *countIn : f.npix;
     const uint32_t lane       = threadIdx.x & 63;
     const uint32_t waveId     = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -258,17 +267,10 @@ __global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const 
                     // primary miss — pathRT.rgen:693-697
                     const uint32_t x = px % f.w, y = px / f.w;
                     const float    u = ((float)x + 0.5f) / (float)f.w, v = ((float)y + 0.5f) / (float)f.h;
-                    if(literal)
-                    {
-                        f.accum[px] = make_float4(u, v, 0.4f, 1.0f);
-                        f.dead[px]  = 1;
-                    }
-                    else
-                    {
-                        const float4 E = f.accum[px];
-                        f.accum[px]    = make_float4(E.x + u, E.y + v, E.z + 0.4f, E.w + 1.0f);
-                        f.dead[px]     = 1;
-                    }
+                    // literal: the miss colour replaces E; default: it is one more term of the sum
+                    f.contrib[px] = make_float4(u, v, 0.4f, 1.0f);
+                    f.nvert[px]   = (uint8_t)((f.nvert[px] & 0x80) | (literal ? 0x41 : 0x01));
+                    f.dead[px]    = 1;
                 }
             }
             else
@@ -433,7 +435,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const 
                     colorw              = colorw / weight;
                 }
 
-                // accumulate — :939-942; the shadow kernel picks one of the two and adds it to E
+                // accumulate — :939-942; the shadow kernel picks one of the two, k_resolve adds it to E
                 const f3 em  = mk3(mat.emission[0], mat.emission[1], mat.emission[2]) * ubo->lightOtherE;
                 const f3 tc  = throughput * color;
                 f3       EiO = mk3(0.0f) + em;
@@ -442,8 +444,9 @@ __global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const 
                 EiV          = EiV * tc;
                 f.shO[px]    = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, colorw);
                 f.shD[px]    = make_float4(vLight.x, vLight.y, vLight.z, 0.0f);
-                f.eiVis[px]  = make_float4(EiV.x, EiV.y, EiV.z, 0.0f);
-                f.eiOcc[px]  = make_float4(EiO.x, EiO.y, EiO.z, 0.0f);
+                f.eiVis[px]  = make_float4(EiV.x, EiV.y, EiV.z, colorw);
+                f.contrib[(size_t)bounce * f.npix + px] = make_float4(EiO.x, EiO.y, EiO.z, colorw);
+                f.nvert[px]  = (uint8_t)((f.nvert[px] & 0x80) | (bounce + 1u));
                 shadowQ      = true;
 
                 // termination — :944-961
@@ -490,6 +493,7 @@ struct ShadowIO
 {
     const FrameView& f;
     const uint32_t*  queue;
+    float4*          term;  // contrib + bounce * npix
     PRT_DEV bool load(uint32_t i, f3& o, float& tmin, f3& d, float& tmax, uint32_t& tag) const
     {
         const uint32_t px = ld_nt(queue + i);
@@ -503,9 +507,7 @@ struct ShadowIO
     }
     PRT_DEV void store(uint32_t px, const Hit& h) const
     {
-        const float4 Ei = (h.prim != 0xffffffffu) ? ld_nt(f.eiOcc + px) : ld_nt(f.eiVis + px);
-        const float4 E  = ld_nt(f.accum + px);
-        st_nt(f.accum + px, make_float4(E.x + Ei.x, E.y + Ei.y, E.z + Ei.z, E.w + ld_nt(f.shO + px).w));
+        if(h.prim == 0xffffffffu) st_nt(term + px, ld_nt(f.eiVis + px));  // visible: Ei_occ -> Ei_vis
     }
 };
 
@@ -513,24 +515,49 @@ template <bool INSTR>
 __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_shadow(SceneView sc, FrameView f,
                                                             const uint32_t* __restrict__ queue,
                                                             const uint32_t* __restrict__ countPtr, uint32_t* workCtr,
-                                                            TraceTune tune)
+                                                            uint32_t bounce, TraceTune tune)
 {
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     const uint32_t      count = *countPtr;
     uint32_t            nrays = 0;
     TraceCount          tc    = {0u, 0u};
-    ShadowIO            io{f, queue};
+    ShadowIO            io{f, queue, f.contrib + (size_t)bounce * f.npix};
     trace_stream<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nrays, tc);
     flush_counts<INSTR>(f, nrays, tc, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
+// resolve — E += Ei of every path vertex, in path order (pathRT.rgen:939-942, :649-654, :693-697, :973)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_resolve(float4* __restrict__ accum, const float4* __restrict__ contrib,
+                                                 const uint8_t* __restrict__ nvert, uint32_t npix)
+{
+    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x;
+    if(px >= npix) return;
+    const uint32_t n = nvert[px];
+    if(n == 0) return;
+    float4 E = (n & 0x80u) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : accum[px];
+    if(n & 0x40u)
+        E = ld_nt(contrib + px);
+    else
+    {
+        const uint32_t cnt = n & 0x3fu;
+        for(uint32_t b = 0; b < cnt; ++b)
+        {
+            const float4 t = ld_nt(contrib + (size_t)b * npix + px);
+            E              = make_float4(E.x + t.x, E.y + t.y, E.z + t.z, E.w + t.w);
+        }
+    }
+    accum[px] = E;
+}
+
+// ---------------------------------------------------------------------------------------------
 // AO — AO.rgen:214-272, after k_ao_generate + k_extend
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, FrameView f,
-                                                              const prt_uniforms* __restrict__ ubo, uint32_t flags,
-                                                              uint32_t* workCtr)
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, FrameView f, const prt_uniforms ubo_,
+                                                              uint32_t flags, uint32_t* workCtr)
 {
+    const prt_uniforms* ubo = &ubo_;
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     const uint32_t      count   = f.npix;
     const int           lane    = threadIdx.x & 63;

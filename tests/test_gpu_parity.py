@@ -146,6 +146,28 @@ def test_path_and_ao_bit_exact(po, case):
         _render_both(po, scenes.random_soup(3000), 128, 96, 1, [0, 2, 3], ao_rays=7, ao_length=2.5)
 
 
+def test_pipelined_iterations_equal_sequential():
+    """Iterations in flight on several streams (prt_set_pipeline_depth) sum in iteration order: bit-identical."""
+    sc = scenes.conference_room(detail=0.4)
+    W, H = 320, 180
+    out = []
+    for depth in (1, 4, 8):
+        ctx = capi.Context(W, H)
+        ctx.set_scene(sc)
+        ctx.set_seed(9)
+        ctx.build_accel()
+        ctx.set_pipeline_depth(depth)
+        ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=5))
+        ctx.render(capi.MODE_PATH, 1, 11, 1)
+        ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=2, iteration=12))  # fewer terms per pass
+        ctx.render_iteration(capi.MODE_PATH)
+        out.append((ctx.read_accum().tobytes(), ctx.stats().rays, ctx.read_hit_ids().tobytes()))
+        ctx.close()
+    assert out[0] == out[1] == out[2]
+    with pytest.raises(capi.PrtError):
+        capi.Context(8, 8).set_pipeline_depth(99)
+
+
 def test_uploaded_scramble_table(po):
     """The reference's explicit 32-layer scramble image (vkRTX_setup.cpp:808-911) instead of the hash."""
     sc = scenes.cornell_box()
