@@ -56,6 +56,7 @@ struct prt_context
     uint32_t*     dIdx   = nullptr;
     prt_material* dMats  = nullptr;
     TexDesc*      dTex   = nullptr;
+    float4*       dShadeTris = nullptr;  // 7 x float4 per triangle (k_gather_shading)
     std::vector<void*> texMem;
     uint32_t      nverts = 0, ntri = 0, nmats = 0, ntex = 0;
     bool          haveScene = false, haveAccel = false;
@@ -72,6 +73,7 @@ struct prt_context
 
     // sampling
     uint32_t* dSobol    = nullptr;
+    uint32_t* dSobolBytes = nullptr;  // [64][4][256] byte tables of the same matrices
     uint32_t* dScramble = nullptr;
 
     // frame
@@ -218,6 +220,7 @@ static void free_scene(prt_context* c)
     dfree(c->dIdx);
     dfree(c->dMats);
     dfree(c->dTex);
+    dfree(c->dShadeTris);
     for(void* p : c->texMem) (void)hipFree(p);
     c->texMem.clear();
     dfree(c->dBuildNodes);
@@ -279,6 +282,18 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
         uint32_t tbl[64 * 32];
         build_sobol_matrices(tbl);
         e = hipMemcpy(c->dSobol, tbl, sizeof tbl, hipMemcpyHostToDevice);
+        std::vector<uint32_t> bytes((size_t)64 * 4 * 256);
+        for(int d = 0; d < 64; ++d)
+            for(int b = 0; b < 4; ++b)
+                for(int v = 0; v < 256; ++v)
+                {
+                    uint32_t x = 0;
+                    for(int j = 0; j < 8; ++j)
+                        if(v & (1 << j)) x ^= tbl[d * 32 + 8 * b + j];
+                    bytes[((size_t)d * 4 + b) * 256 + v] = x;
+                }
+        if(e == hipSuccess) e = dalloc(c->dSobolBytes, bytes.size());
+        if(e == hipSuccess) e = hipMemcpy(c->dSobolBytes, bytes.data(), bytes.size() * 4, hipMemcpyHostToDevice);
     }
     if(e == hipSuccess) e = hipMemset(c->accumOwn, 0, n * sizeof(float4));
     if(e == hipSuccess) e = hipMemset(c->stats, 0, kStatWords * sizeof(unsigned long long));
@@ -316,6 +331,7 @@ int prt_destroy(prt_context* c)
     dfree(c->batchCounter);
     dfree(c->stats);
     dfree(c->dSobol);
+    dfree(c->dSobolBytes);
     dfree(c->dScramble);
     prof_collect(c);
     for(hipEvent_t e : c->eventPool) (void)hipEventDestroy(e);
@@ -363,6 +379,11 @@ int prt_set_scene(prt_context* c, const prt_vertex* v, size_t nv, const uint32_t
     }
     HIPCHK(c, dalloc(c->dTex, ntex));
     if(ntex) HIPCHK(c, hipMemcpy(c->dTex, td.data(), ntex * sizeof(TexDesc), hipMemcpyHostToDevice));
+    HIPCHK(c, dalloc(c->dShadeTris, (size_t)c->ntri * 7));
+    hipLaunchKernelGGL(k_gather_shading, dim3(cdiv(c->ntri, 256)), dim3(256), 0, c->stream, c->dVerts, c->dIdx, c->ntri,
+                       c->dShadeTris);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->haveScene = true;
     return PRT_OK;
 }
@@ -624,6 +645,8 @@ struct ProfScope
 
 static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& f)
 {
+    sc.stri         = c->dShadeTris;
+    sc.sobolBytes   = c->dSobolBytes;
     sc.verts        = c->dVerts;
     sc.idx          = c->dIdx;
     sc.mats         = c->dMats;

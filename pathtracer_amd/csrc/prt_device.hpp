@@ -127,6 +127,16 @@ PRT_DEV float sobol1D(const uint32_t* __restrict__ M, uint32_t index, uint32_t d
     return (float)result * 2.3283064365386963e-10f;
 }
 
+// The same sample from byte tables: T[b][v] = XOR of the matrix words 8b+j over the set bits j of v, so
+// four table reads replace the 32-step loop (XOR is exact: bit-identical). `T` is the dimension's
+// [4][256] table, staged in LDS by the shade kernel.
+PRT_DEV float sobol1D_bytes(const uint32_t* T, uint32_t index, uint32_t scramble)
+{
+    const uint32_t result = scramble ^ T[index & 255u] ^ T[256u + ((index >> 8) & 255u)]
+                            ^ T[512u + ((index >> 16) & 255u)] ^ T[768u + (index >> 24)];
+    return (float)result * 2.3283064365386963e-10f;
+}
+
 PRT_DEV uint32_t lowbias32(uint32_t x)
 {
     x ^= x >> 16;

@@ -31,6 +31,8 @@ namespace prt {
 
 struct SceneView
 {
+    const float4*       stri;  // 7 x float4 per triangle: p,n,t of the three corners + material id of corner 1
+    const uint32_t*     sobolBytes;  // [64][4][256]
     const prt_vertex*   verts;
     const uint32_t*     idx;
     const prt_material* mats;
@@ -76,6 +78,30 @@ PRT_DEV uint32_t wave_push(bool pred, uint32_t* counter)
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// Block-wide variant (all 256 threads call it): one atomic per block instead of one per wave — the
+// counters are single addresses, and same-address atomics serialise at the memory side.
+PRT_DEV uint32_t block_push(bool pred, uint32_t* counter, uint32_t* lds /*[8]*/)
+{
+    const unsigned long long mask = __ballot(pred);
+    const int                lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if(lane == 0) lds[wid] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if(threadIdx.x == 0)
+    {
+        const uint32_t n0 = lds[0], n1 = lds[1], n2 = lds[2], n3 = lds[3];
+        const uint32_t tot = n0 + n1 + n2 + n3;
+        const uint32_t b   = tot ? atomicAdd(counter, tot) : 0u;
+        lds[4] = b;
+        lds[5] = b + n0;
+        lds[6] = b + n0 + n1;
+        lds[7] = b + n0 + n1 + n2;
+    }
+    __syncthreads();
+    const uint32_t base = lds[4 + wid];
+    __syncthreads();
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
 PRT_DEV uint32_t wave_fetch(uint32_t* workCtr)
 {
     uint32_t base = 0;
@@ -90,19 +116,23 @@ PRT_DEV uint32_t wave_sum(uint32_t v)
     for(int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
     return v;
 }
+// `queued` = length of the launch's queue, `rays` = rays this lane loaded that count in the statistics. The total
+// is added once per launch; a wave only touches the counter for the (rare) placeholder rays it must take off
+// again — one same-address atomic per wave at the end of every launch is a measurable tail otherwise.
 template <bool INSTR>
-PRT_DEV void flush_counts(const FrameView& f, uint32_t rays, TraceCount tc, int kind)
+PRT_DEV void flush_counts(const FrameView& f, uint32_t queued, uint32_t skippedLane, TraceCount tc, int kind)
 {
-    const uint32_t r = wave_sum(rays);
+    const uint32_t skipped = wave_sum(skippedLane);
     uint32_t       n = 0, t = 0;
     if(INSTR)
     {
         n = wave_sum(tc.nodes);
         t = wave_sum(tc.tris);
     }
+    if(blockIdx.x == 0 && threadIdx.x == 0 && queued) atomicAdd(f.stats + kind, (unsigned long long)queued);
     if((threadIdx.x & 63) == 0)
     {
-        if(r) atomicAdd(f.stats + kind, (unsigned long long)r);
+        if(skipped) atomicAdd(f.stats + kind, ~(unsigned long long)skipped + 1ull);
         if(INSTR)
         {
             atomicAdd(f.stats + 2 + 2 * kind, (unsigned long long)n);
@@ -204,11 +234,11 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_extend(Sce
 {
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     const uint32_t      count = countPtr ? *countPtr : f.npix;
-    uint32_t            nrays = 0;
+    uint32_t            nskip = 0;
     TraceCount          tc    = {0u, 0u};
     ExtendIO            io{f, queue, primary};
-    trace_stream<false, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nrays, tc);
-    flush_counts<INSTR>(f, nrays, tc, 0);
+    trace_stream<false, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nskip, tc);
+    flush_counts<INSTR>(f, count, nskip, tc, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -216,42 +246,86 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_extend(Sce
 // ---------------------------------------------------------------------------------------------
 struct VertexU
 {
-    f3      pos, normal;
-    f2      uv;
+    f3 pos, normal;
+    f2 uv;
+};
+// Shading record of one triangle, gathered once at prt_set_scene from the vertex/index buffers
+// (unpackVertex, pathRT.rgen:94-119): corner k = rows 2k, 2k+1 = (p.xyz, n.x), (n.y, n.z, t.x, t.y);
+// row 6.x = materialID of corner 1 (the shader takes the material from v1, :712).
+struct TriU
+{
+    VertexU v0, v1, v2;
     int32_t mat;
 };
-PRT_DEV VertexU load_vertex(const prt_vertex* __restrict__ verts, uint32_t index)
+PRT_DEV VertexU unpack_corner(float4 a, float4 b)
 {
-    const float4* q  = (const float4*)(verts + index);  // 48-byte records, 16-byte aligned
-    const float4  d0 = q[0], d1 = q[1], d2 = q[2];
-    VertexU       v;
-    v.pos    = mk3(d0.x, d0.y, d0.z);
-    v.normal = mk3(d0.w, d1.x, d1.y);
-    v.uv.x   = d1.z;
-    v.uv.y   = d1.w;
-    v.mat    = __float_as_int(d2.w);
+    VertexU v;
+    v.pos    = mk3(a.x, a.y, a.z);
+    v.normal = mk3(a.w, b.x, b.y);
+    v.uv.x   = b.z;
+    v.uv.y   = b.w;
     return v;
 }
+PRT_DEV TriU load_tri(const float4* __restrict__ stri, uint32_t prim)
+{
+    const float4* q  = stri + (size_t)prim * 7;
+    const float4  q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+    TriU          t;
+    t.v0  = unpack_corner(q0, q1);
+    t.v1  = unpack_corner(q2, q3);
+    t.v2  = unpack_corner(q4, q5);
+    t.mat = __float_as_int(q6.x);
+    return t;
+}
+__global__ void __launch_bounds__(256) k_gather_shading(const prt_vertex* __restrict__ verts,
+                                                        const uint32_t* __restrict__ idx, uint32_t ntri,
+                                                        float4* __restrict__ stri)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= ntri) return;
+    float4* o = stri + (size_t)i * 7;
+    for(int k = 0; k < 3; ++k)
+    {
+        const prt_vertex& v = verts[idx[3 * i + k]];
+        o[2 * k]            = make_float4(v.p[0], v.p[1], v.p[2], v.n[0]);
+        o[2 * k + 1]        = make_float4(v.n[1], v.n[2], v.t[0], v.t[1]);
+    }
+    o[6] = make_float4(__int_as_float(verts[idx[3 * i + 1]].materialID), 0.0f, 0.0f, 0.0f);
+}
 
-__global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,
+#ifndef PRT_SHADE_WAVES
+#define PRT_SHADE_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,
                                                uint32_t bounce, const uint32_t* __restrict__ queueIn,
                                                const uint32_t* __restrict__ countIn, uint32_t* __restrict__ queueNext,
                                                uint32_t* countNext, uint32_t* __restrict__ queueShadow,
                                                uint32_t* countShadow)
 {
     const prt_uniforms* ubo = &ubo_;
+    // Sobol byte tables of this vertex's dimensions (4 + 4*bounce .. +3) and of the roulette dimension
+    __shared__ uint32_t sobT[5 * 1024];
+    {
+        const uint32_t dim0 = 4u + 4u * bounce, dimR = 48u + bounce + 1u;
+        for(uint32_t k = threadIdx.x; k < 5u * 1024u; k += 256u)
+        {
+            const uint32_t d = k >> 10;
+            const uint32_t g = d < 4u ? dim0 + d : dimR;
+            sobT[k]          = g < 64u ? sc.sobolBytes[g * 1024u + (k & 1023u)] : 0u;
+        }
+        __syncthreads();
+    }
     const uint32_t count      = countIn ? *countIn : f.npix;
     const uint32_t lane       = threadIdx.x & 63;
-    const uint32_t waveId     = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t waveCount  = (gridDim.x * blockDim.x) >> 6;
+    __shared__ uint32_t pushLds[8];
     const bool     literal    = (flags & PRT_FLAG_LITERAL) != 0;
     const bool     rr         = (flags & PRT_FLAG_RUSSIAN_ROULETTE) != 0;
     const int      maxBounces = ubo->numIndirectBounces;
     const int      numAA      = ubo->numAArays;
 
-    for(uint32_t base = waveId * 64u; base < count; base += waveCount * 64u)
+    for(uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u)  // block-uniform trip count
     {
-        const uint32_t i       = base + lane;
+        const uint32_t i       = base + threadIdx.x;
         bool           shadowQ = false, nextQ = false;
         uint32_t       px      = 0;
         if(i < count)
@@ -289,12 +363,11 @@ __global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const 
                 const uint32_t layer = 1u + bounce;  // scrambleArray[scrambleArrayLayer++], :664,:703
                 const uint32_t scr0  = scramble_value(sc.scrTable, f.npix, sc.seed, px, 2u * layer);
                 const uint32_t scr1  = scramble_value(sc.scrTable, f.npix, sc.seed, px, 2u * layer + 1u);
-                const uint32_t dim   = 4u + 4u * bounce;  // sobolDim after the pixel offset, 4 per vertex
+                // sobolDim after the pixel offset is 4 + 4*bounce, 4 per vertex: tables 0..3 of sobT
 
-                const VertexU v0 = load_vertex(sc.verts, sc.idx[3u * primitiveID]);
-                const VertexU v1 = load_vertex(sc.verts, sc.idx[3u * primitiveID + 1u]);
-                const VertexU v2 = load_vertex(sc.verts, sc.idx[3u * primitiveID + 2u]);
-                const uint32_t      mi  = (v1.mat >= 0 && (uint32_t)v1.mat < sc.nmats) ? (uint32_t)v1.mat : 0u;
+                const TriU     tri = load_tri(sc.stri, primitiveID);
+                const VertexU &v0 = tri.v0, &v1 = tri.v1, &v2 = tri.v2;
+                const uint32_t      mi  = (tri.mat >= 0 && (uint32_t)tri.mat < sc.nmats) ? (uint32_t)tri.mat : 0u;
                 const prt_material& mat = sc.mats[mi];
 
                 f3 sNormal = normalize3((v0.normal * bary.x + v1.normal * bary.y) + v2.normal * bary.z);
@@ -343,8 +416,8 @@ __global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const 
 
                 // light sample — :798-805, sampleLight :304-309
                 f2 s;
-                s.x = sobol1D(sc.sobol, sidx, dim + 0u, scr0);
-                s.y = sobol1D(sc.sobol, sidx, dim + 1u, scr1);
+                s.x = sobol1D_bytes(sobT, sidx, scr0);
+                s.y = sobol1D_bytes(sobT + 1024, sidx, scr1);
                 float       pdf = 1.0f / (4.0f * ubo->lightSize[0] * ubo->lightSize[1]);
                 const float lpx = (s.x * 2.0f - 1.0f) * ubo->lightSize[0];
                 const float lpy = (s.y * 2.0f - 1.0f) * ubo->lightSize[1];
@@ -381,8 +454,8 @@ __global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const 
                 f3 specularBRDF = mk3(0.0f);
                 {
                     f2 rnd;
-                    rnd.x       = sobol1D(sc.sobol, sidx, dim + 2u, scr0);
-                    rnd.y       = sobol1D(sc.sobol, sidx, dim + 3u, scr1);
+                    rnd.x       = sobol1D_bytes(sobT + 2048, sidx, scr0);
+                    rnd.y       = sobol1D_bytes(sobT + 3072, sidx, scr1);
                     const f3 wm = ggx_sample_vndf(wo, alpha, rnd);
                     const float fres = ggx_fresnel_dielectric(wo.z, 1.0f, 1.45f);
                     if(mat.dissolve == 0.0f)
@@ -464,7 +537,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const 
                     const uint32_t b1  = bounce + 1u;
                     const uint32_t rs  = scramble_value(sc.scrTable, f.npix, sc.seed, px, 30u + (b1 & 1u));
                     const float    q   = gclamp(maxcoord(throughput), 0.05f, 1.0f);
-                    const float    xi  = sobol1D(sc.sobol, sidx, 48u + b1, rs);
+                    const float    xi  = sobol1D_bytes(sobT + 4096, sidx, rs);
                     if(xi >= q)
                         alive = false;
                     else
@@ -479,9 +552,9 @@ __global__ void __launch_bounds__(256) k_shade(SceneView sc, FrameView f, const 
                 }
             }
         }
-        const uint32_t si = wave_push(shadowQ, countShadow);
+        const uint32_t si = block_push(shadowQ, countShadow, pushLds);
         if(shadowQ) queueShadow[si] = px;
-        const uint32_t ni = wave_push(nextQ, countNext);
+        const uint32_t ni = block_push(nextQ, countNext, pushLds);
         if(nextQ) queueNext[ni] = px;
     }
 }
@@ -519,11 +592,11 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_shadow(Sce
 {
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     const uint32_t      count = *countPtr;
-    uint32_t            nrays = 0;
+    uint32_t            nskip = 0;
     TraceCount          tc    = {0u, 0u};
     ShadowIO            io{f, queue, f.contrib + (size_t)bounce * f.npix};
-    trace_stream<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nrays, tc);
-    flush_counts<INSTR>(f, nrays, tc, 1);
+    trace_stream<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nskip, tc);
+    flush_counts<INSTR>(f, count, nskip, tc, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -585,9 +658,8 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
                 const uint32_t scr0 = scramble_value(sc.scrTable, f.npix, sc.seed, px, 0);
                 const uint32_t scr1 = scramble_value(sc.scrTable, f.npix, sc.seed, px, 1);
                 uint32_t sobolIndex = scramble_value(sc.scrTable, f.npix, sc.seed, px, 2);
-                const VertexU v0 = load_vertex(sc.verts, sc.idx[3u * prim]);
-                const VertexU v1 = load_vertex(sc.verts, sc.idx[3u * prim + 1u]);
-                const VertexU v2 = load_vertex(sc.verts, sc.idx[3u * prim + 2u]);
+                const TriU     tri = load_tri(sc.stri, prim);
+                const VertexU &v0 = tri.v0, &v1 = tri.v1, &v2 = tri.v2;
                 const f3      bary = mk3(1.0f - hq.y - hq.z, hq.y, hq.z);
                 const float4  rd4  = f.rayD[px];
                 f3 normal = normalize3((v0.normal * bary.x + v1.normal * bary.y) + v2.normal * bary.z);
@@ -630,7 +702,10 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
             }
         }
     }
-    flush_counts<false>(f, nrays, TraceCount{0u, 0u}, 1);
+    {
+        const uint32_t r = wave_sum(nrays);
+        if((threadIdx.x & 63) == 0 && r) atomicAdd(f.stats + 1, (unsigned long long)r);
+    }
 }
 
 // pathRTpostprocess.comp:38-51 over the whole image (the reference's W/16 x H/16 dispatch drops
@@ -688,10 +763,10 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_trace_batc
                                                                  uint32_t* workCtr, TraceTune tune)
 {
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
-    uint32_t            nrays = 0;
+    uint32_t            nskip = 0;
     TraceCount          tc    = {0u, 0u};
     BatchIO             io{rays, hits};
-    trace_stream<ANY, false>(bvh, &stackLds[threadIdx.x], n, workCtr, tune, io, nrays, tc);
+    trace_stream<ANY, false>(bvh, &stackLds[threadIdx.x], n, workCtr, tune, io, nskip, tc);
 }
 
 }  // namespace prt

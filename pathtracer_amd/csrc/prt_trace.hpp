@@ -37,7 +37,9 @@ namespace prt {
 #define PRT_TRACE_WAVES 4  // minimum waves per SIMD the traversal kernels are compiled for
 #endif
 #define PRT_NODE_BYTES 64
+#ifndef PRT_CHUNK
 #define PRT_CHUNK 128u
+#endif
 
 static_assert(1 + 3 * (PRT_MAX_DEPTH / 2 + 1) <= 24 + PRT_SPILL_STACK && PRT_LDS_STACK >= 8, "stack covers the deepest tree");
 
@@ -368,11 +370,11 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, f3 o, float tmin, f3 d,
 }
 
 // ---- persistent wave: a stream of `count` rays ----------------------------------------------------------
-// IO::load(i, o, tmin, d, tmax, tag) -> bool (true: the ray counts in the statistics);
+// IO::load(i, o, tmin, d, tmax, tag) -> bool (false: a placeholder that does not count in the statistics);
 // IO::store(tag, hit) is called once per ray when it has finished.
 template <bool ANY, bool INSTR, class IO>
 PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uint32_t* workCtr, const TraceTune tune,
-                          IO& io, uint32_t& nrays, TraceCount& tc)
+                          IO& io, uint32_t& nskipped, TraceCount& tc)
 {
     const int                lane   = threadIdx.x & 63;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
@@ -411,7 +413,7 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
             {
                 f3    o, d;
                 float tmin, tmax;
-                if(io.load(chunkPos + rank, o, tmin, d, tmax, tag)) nrays++;
+                if(!io.load(chunkPos + rank, o, tmin, d, tmax, tag)) nskipped++;
                 ray_prepare(bvh, o, tmin, d, tmax, r);
                 best   = hit_none(tmax);
                 cur    = bvh.root;
