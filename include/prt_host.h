@@ -1,0 +1,71 @@
+/* prt_host.h — C view of the headless host layer (libprt_host.so, sources in pathtracer_amd/host/).
+ *
+ * The host layer itself is C++ with the reference's scene API (Model, AreaLight, CameraControls, the
+ * vkContext settings block; see the headers in pathtracer_amd/host/); these entry points exist so that tests, tools and
+ * foreign-language callers can reach the same code through plain pointers and sizes. Each one names the
+ * reference code it stands for. Functions return 0 on success, a negative value on failure.
+ */
+#ifndef PRT_HOST_H
+#define PRT_HOST_H
+
+#include "prt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct prth_model prth_model;
+
+/* VkTools::Model::Model(ctx, path) — /root/reference/src/Model.h:132-139: LoadModelFromFile + createTextures
+ * (Model.cpp:47-221, 311-387). `err` receives the loader's message when the OBJ cannot be read. */
+int  prth_model_load(const char* obj_path, prth_model** out, char* err, size_t err_len);
+void prth_model_free(prth_model* m);
+size_t              prth_model_num_vertices(const prth_model* m);  /* Model::m_vertices */
+size_t              prth_model_num_indices(const prth_model* m);   /* Model::m_indices */
+size_t              prth_model_num_materials(const prth_model* m); /* Model::m_materials */
+size_t              prth_model_num_textures(const prth_model* m);  /* Model::m_textures */
+const prt_vertex*   prth_model_vertices(const prth_model* m);
+const uint32_t*     prth_model_indices(const prth_model* m);
+const prt_material* prth_model_materials(const prth_model* m);
+/* Model::m_textures[i] (RGBA8 pixels, size) and Model::m_texturePaths[i] ("" for the 1x1 white stand-in). */
+int prth_model_texture(const prth_model* m, size_t i, prt_texture* out, const char** path);
+const char* prth_model_warnings(const prth_model* m);
+
+/* What the OBJ/MTL reader (tinyobj::LoadObj at Model.cpp:54) yields for a file, written as JSON. */
+int prth_obj_dump_json(const char* obj_path, const char* mtl_dir, const char* json_path);
+
+/* stbi_load(path, &w, &h, &channels, STBI_rgb_alpha) — Model.cpp:350. *rgba is released with prth_free. */
+int  prth_image_load(const char* path, uint32_t* width, uint32_t* height, uint8_t** rgba);
+void prth_free(void* p);
+
+/* The reference's settings block (vkContext.h:161-192), as plain data. */
+typedef struct prth_settings
+{
+    int32_t  numIndicesBounces, samplesPerPixel, numAArays;
+    float    filterRadius;
+    int32_t  numAOrays;
+    float    aoRayLength, lightSourceArea, lightE, lightOtherE;
+    int32_t  rtRenderingMode;
+    uint32_t iteration;
+} prth_settings;
+void prth_default_settings(prth_settings* s);
+
+/* CameraControls (CameraControls.cpp:35-41, 111-126) at a pose + vkContext::updateGraphicsUniforms
+ * (vkContext.cpp:993-1060) with the light captured from the camera (m_moveLight): the 464-byte block, and the
+ * un-flipped camera projection. yaw / pitch in degrees. */
+int prth_camera_uniforms(float fov_deg, float aspect, float z_near, float z_far, const float position[3], float yaw_deg,
+                         float pitch_deg, const prth_settings* settings, prt_uniforms* ubo_out, float projection_out[16]);
+
+/* Whole path: Model -> Renderer::initRaytracing -> n iterations from `first_iteration` -> accumulation image
+ * (width*height*4 floats). The camera sits at `eye` looking at `target`; the light is an AreaLight at `light_pos`
+ * facing `light_dir` when light_pos != NULL, else it is captured from the camera. ubo_out (optional) receives
+ * the block of the first iteration. Needs a GPU. */
+int prth_render_obj(const char* obj_path, int device, uint32_t width, uint32_t height, const prth_settings* settings,
+                    const float eye[3], const float target[3], const float* light_pos, const float* light_dir,
+                    uint32_t first_iteration, uint32_t n_iterations, float* accum_out, prt_uniforms* ubo_out, char* err,
+                    size_t err_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRT_HOST_H */

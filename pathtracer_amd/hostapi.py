@@ -1,0 +1,145 @@
+"""ctypes binding of include/prt_host.h (libprt_host.so): the C++ host layer — Model / CameraControls /
+AreaLight / Renderer of the reference's scene API. Plumbing for tests and tools; no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import scenes, uniforms
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprt_host.so")
+
+EXPORTS = [
+    "prth_model_load", "prth_model_free", "prth_model_num_vertices", "prth_model_num_indices",
+    "prth_model_num_materials", "prth_model_num_textures", "prth_model_vertices", "prth_model_indices",
+    "prth_model_materials", "prth_model_texture", "prth_model_warnings", "prth_obj_dump_json", "prth_image_load",
+    "prth_free", "prth_default_settings", "prth_camera_uniforms", "prth_render_obj",
+]
+
+
+class Settings(C.Structure):
+    _fields_ = [("numIndicesBounces", C.c_int32), ("samplesPerPixel", C.c_int32), ("numAArays", C.c_int32),
+                ("filterRadius", C.c_float), ("numAOrays", C.c_int32), ("aoRayLength", C.c_float),
+                ("lightSourceArea", C.c_float), ("lightE", C.c_float), ("lightOtherE", C.c_float),
+                ("rtRenderingMode", C.c_int32), ("iteration", C.c_uint32)]
+
+
+class _Tex(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class HostError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise HostError(f"{LIB_PATH} is missing: build it with `make -C pathtracer_amd/host`")
+        L = C.CDLL(LIB_PATH)
+        vp, sz = C.c_void_p, C.c_size_t
+        L.prth_model_load.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, sz]
+        L.prth_model_free.argtypes = [vp]
+        L.prth_model_free.restype = None
+        for n in ("vertices", "indices", "materials", "textures"):
+            f = getattr(L, "prth_model_num_" + n)
+            f.argtypes, f.restype = [vp], sz
+        for n in ("vertices", "indices", "materials"):
+            f = getattr(L, "prth_model_" + n)
+            f.argtypes, f.restype = [vp], vp
+        L.prth_model_texture.argtypes = [vp, sz, C.POINTER(_Tex), C.POINTER(C.c_char_p)]
+        L.prth_model_warnings.argtypes = [vp]
+        L.prth_model_warnings.restype = C.c_char_p
+        L.prth_obj_dump_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+        L.prth_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(vp)]
+        L.prth_free.argtypes = [vp]
+        L.prth_free.restype = None
+        L.prth_default_settings.argtypes = [C.POINTER(Settings)]
+        L.prth_default_settings.restype = None
+        fp = C.POINTER(C.c_float)
+        L.prth_camera_uniforms.argtypes = [C.c_float] * 4 + [fp, C.c_float, C.c_float, C.POINTER(Settings), vp, fp]
+        L.prth_render_obj.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(Settings), fp, fp, fp, fp,
+                                      C.c_uint32, C.c_uint32, vp, vp, C.c_char_p, sz]
+        _LIB = L
+    return _LIB
+
+
+def default_settings(**kw):
+    s = Settings()
+    lib().prth_default_settings(C.byref(s))
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+def load_model(obj_path):
+    """Model(path): returns a scene dict in the layout of pathtracer_amd.scenes (vertices / indices / materials /
+    textures as numpy arrays) plus texture paths and loader warnings."""
+    L = lib()
+    h = C.c_void_p()
+    err = C.create_string_buffer(1024)
+    if L.prth_model_load(os.fsencode(obj_path), C.byref(h), err, len(err)) != 0:
+        raise HostError(err.value.decode(errors="replace"))
+    try:
+        nv, ni, nm, nt = (getattr(L, "prth_model_num_" + n)(h) for n in ("vertices", "indices", "materials", "textures"))
+        v = np.frombuffer(C.string_at(L.prth_model_vertices(h), nv * 48), scenes.VERTEX_DTYPE).copy() if nv else np.zeros(0, scenes.VERTEX_DTYPE)
+        i = np.frombuffer(C.string_at(L.prth_model_indices(h), ni * 4), np.uint32).copy() if ni else np.zeros(0, np.uint32)
+        m = np.frombuffer(C.string_at(L.prth_model_materials(h), nm * 96), scenes.MATERIAL_DTYPE).copy()
+        texs, paths = [], []
+        for k in range(nt):
+            t, p = _Tex(), C.c_char_p()
+            L.prth_model_texture(h, k, C.byref(t), C.byref(p))
+            texs.append(np.frombuffer(C.string_at(t.rgba, t.width * t.height * 4), np.uint8).reshape(t.height, t.width, 4).copy())
+            paths.append(p.value.decode())
+        return {"vertices": v, "indices": i, "materials": m, "textures": texs, "texture_paths": paths,
+                "warnings": L.prth_model_warnings(h).decode(errors="replace"), "name": os.path.basename(obj_path)}
+    finally:
+        L.prth_model_free(h)
+
+
+def load_image(path):
+    w, h, p = C.c_uint32(), C.c_uint32(), C.c_void_p()
+    if lib().prth_image_load(os.fsencode(path), C.byref(w), C.byref(h), C.byref(p)) != 0:
+        return None
+    try:
+        return np.frombuffer(C.string_at(p, w.value * h.value * 4), np.uint8).reshape(h.value, w.value, 4).copy()
+    finally:
+        lib().prth_free(p)
+
+
+def camera_uniforms(fov, aspect, near, far, pos, yaw, pitch, settings=None):
+    s = settings or default_settings()
+    ubo = np.zeros((), uniforms.UBO_DTYPE)
+    proj = np.zeros(16, np.float32)
+    pos = np.asarray(pos, np.float32)
+    rc = lib().prth_camera_uniforms(fov, aspect, near, far, pos.ctypes.data_as(C.POINTER(C.c_float)), yaw, pitch, C.byref(s),
+                                    ubo.ctypes.data_as(C.c_void_p), proj.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != 0:
+        raise HostError("prth_camera_uniforms failed")
+    return ubo, proj
+
+
+def render_obj(obj_path, width, height, settings, eye, target, light=None, first=1, n=1, device=0):
+    fp = C.POINTER(C.c_float)
+    a = lambda x: np.asarray(x, np.float32)
+    eye, target = a(eye), a(target)
+    lp = ld = None
+    if light is not None:
+        lp, ld = a(light[0]), a(light[1])
+    accum = np.zeros((height, width, 4), np.float32)
+    ubo = np.zeros((), uniforms.UBO_DTYPE)
+    err = C.create_string_buffer(1024)
+    rc = lib().prth_render_obj(os.fsencode(obj_path), device, width, height, C.byref(settings), eye.ctypes.data_as(fp),
+                               target.ctypes.data_as(fp), lp.ctypes.data_as(fp) if lp is not None else None,
+                               ld.ctypes.data_as(fp) if ld is not None else None, first, n,
+                               accum.ctypes.data_as(C.c_void_p), ubo.ctypes.data_as(C.c_void_p), err, len(err))
+    if rc != 0:
+        raise HostError(err.value.decode(errors="replace"))
+    return accum, ubo
