@@ -228,36 +228,75 @@ __global__ void __launch_bounds__(256) k_clear_bins(uint32_t* __restrict__ bins,
     bins[i]          = w < 3 * kBins ? 0u : (w < 3 * kBins * 4 ? kKeyPosInf : kKeyNegInf);
 }
 
-// every triangle of a splitting node drops its box into one bin per axis
+// every triangle of a splitting node drops its box into one bin per axis.
+// Triangles are sorted by node, so on the upper levels a whole block belongs to ONE node: its 336 bin words are
+// then accumulated in LDS and flushed with one global atomic per word (same-address global atomics serialise;
+// they were 90 % of the build time). Mixed blocks (lower levels, little contention) go to global memory directly.
+// Integer add / min / max commute, so the bins - and the tree - do not depend on the path taken.
 __global__ void __launch_bounds__(256) k_bin(const uint32_t* __restrict__ order, const uint32_t* __restrict__ nodeOf,
                                              const BuildNode* __restrict__ nodes, const uint32_t* __restrict__ cb,
                                              const float4* __restrict__ pbox, const uint32_t* __restrict__ rank,
                                              uint32_t levelStart, uint32_t ntri, uint32_t* __restrict__ bins)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if(i >= ntri) return;
-    const uint32_t ni = nodeOf[i];
-    if(nodes[ni].count <= kLeafMax) return;
-    const uint32_t p  = order[i];
-    const float4   mn = pbox[2 * p], mx = pbox[2 * p + 1];
-    const float    c[3]  = {(mn.x + mx.x) * 0.5f, (mn.y + mx.y) * 0.5f, (mn.z + mx.z) * 0.5f};
-    const uint32_t km[3] = {fkey(mn.x), fkey(mn.y), fkey(mn.z)};
-    const uint32_t kx[3] = {fkey(mx.x), fkey(mx.y), fkey(mx.z)};
-    uint32_t*      B     = bins + (size_t)rank[ni - levelStart] * kBinWords;
-    for(int a = 0; a < 3; ++a)
+    __shared__ uint32_t lbins[kBinWords];
+    const uint32_t      i     = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t      first = blockIdx.x * blockDim.x;
+    const uint32_t      last  = min(first + blockDim.x, ntri) - 1u;
+    const uint32_t      n0    = nodeOf[first];
+    const bool          uniform = n0 == nodeOf[last];  // block-uniform: sorted by node
+    if(uniform)
     {
-        const float cmin = fdec(cb[6 * ni + a]), cmax = fdec(cb[6 * ni + 3 + a]);
-        const float ext = cmax - cmin;
-        if(!(ext > 0.0f)) continue;
-        const float scale = (float)kBins / ext;
-        const int   b     = bin_of(c[a], cmin, scale);
-        atomicAdd(&B[a * kBins + b], 1u);
-        uint32_t* bmn = B + 3 * kBins + (a * kBins + b) * 3;
-        uint32_t* bmx = B + 3 * kBins * 4 + (a * kBins + b) * 3;
-        for(int k = 0; k < 3; ++k)
+        if(nodes[n0].count <= kLeafMax) return;  // the whole block sits in a finished leaf
+        for(uint32_t w = threadIdx.x; w < kBinWords; w += blockDim.x)
+            lbins[w] = w < 3 * kBins ? 0u : (w < 3 * kBins * 4 ? kKeyPosInf : kKeyNegInf);
+        __syncthreads();
+    }
+    if(i < ntri)
+    {
+        const uint32_t ni = nodeOf[i];
+        if(nodes[ni].count > kLeafMax)
         {
-            atomicMin(&bmn[k], km[k]);
-            atomicMax(&bmx[k], kx[k]);
+            const uint32_t p  = order[i];
+            const float4   mn = pbox[2 * p], mx = pbox[2 * p + 1];
+            const float    c[3]  = {(mn.x + mx.x) * 0.5f, (mn.y + mx.y) * 0.5f, (mn.z + mx.z) * 0.5f};
+            const uint32_t km[3] = {fkey(mn.x), fkey(mn.y), fkey(mn.z)};
+            const uint32_t kx[3] = {fkey(mx.x), fkey(mx.y), fkey(mx.z)};
+            uint32_t*      B     = uniform ? lbins : bins + (size_t)rank[ni - levelStart] * kBinWords;
+            for(int a = 0; a < 3; ++a)
+            {
+                const float cmin = fdec(cb[6 * ni + a]), cmax = fdec(cb[6 * ni + 3 + a]);
+                const float ext = cmax - cmin;
+                if(!(ext > 0.0f)) continue;
+                const float scale = (float)kBins / ext;
+                const int   b     = bin_of(c[a], cmin, scale);
+                atomicAdd(&B[a * kBins + b], 1u);
+                uint32_t* bmn = B + 3 * kBins + (a * kBins + b) * 3;
+                uint32_t* bmx = B + 3 * kBins * 4 + (a * kBins + b) * 3;
+                for(int k = 0; k < 3; ++k)
+                {
+                    atomicMin(&bmn[k], km[k]);
+                    atomicMax(&bmx[k], kx[k]);
+                }
+            }
+        }
+    }
+    if(uniform)
+    {
+        __syncthreads();
+        uint32_t* B = bins + (size_t)rank[n0 - levelStart] * kBinWords;
+        for(uint32_t w = threadIdx.x; w < kBinWords; w += blockDim.x)
+        {
+            const uint32_t v = lbins[w];
+            if(w < 3 * kBins)
+            {
+                if(v) atomicAdd(&B[w], v);
+            }
+            else if(w < 3 * kBins * 4)
+            {
+                if(v != kKeyPosInf) atomicMin(&B[w], v);
+            }
+            else if(v != kKeyNegInf)
+                atomicMax(&B[w], v);
         }
     }
 }
@@ -451,41 +490,98 @@ __global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ or
                                                  uint32_t ntri, uint32_t* __restrict__ orderOut,
                                                  uint32_t* __restrict__ nodeOfOut)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if(i >= ntri) return;
-    const uint32_t ni = nodeOf[i];
-    const uint32_t p  = order[i];
-    uint32_t       s  = 0xffffffffu;
-    if(ni >= levelStart) s = splitOf[ni - levelStart];
-    if(s == 0xffffffffu)
+    // [child 0/1][centroid min 3 | centroid max 3 | box min 3 | box max 3]: block-private when the whole block
+    // belongs to one splitting node (see k_bin)
+    __shared__ uint32_t lcb[2][12];
+    const uint32_t      i     = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t      first = blockIdx.x * blockDim.x;
+    const uint32_t      last  = min(first + blockDim.x, ntri) - 1u;
+    const uint32_t      n0    = nodeOf[first];
+    const bool          uniform = n0 == nodeOf[last];
+    if(uniform)
     {
-        orderOut[i]  = p;
-        nodeOfOut[i] = ni;
-        return;
+        if(threadIdx.x < 24) lcb[threadIdx.x / 12][threadIdx.x % 12] = ((threadIdx.x % 6) < 3) ? kKeyPosInf : kKeyNegInf;
+        __syncthreads();
     }
-    const SplitRec r     = splits[s];
-    const uint32_t start = nodes[r.child].first;
-    const uint32_t lBefore = scanL[i] - scanL[start];
-    const bool     left    = flagsIn[i] != 0u;
-    const uint32_t pos     = left ? start + lBefore : start + r.nL + ((i - start) - lBefore);
-    const uint32_t child   = left ? r.child : r.child + 1;
-    orderOut[pos]          = p;
-    nodeOfOut[pos]         = child;
-    const float4 mn = pbox[2 * p], mx = pbox[2 * p + 1];
-    const float  c[3] = {(mn.x + mx.x) * 0.5f, (mn.y + mx.y) * 0.5f, (mn.z + mx.z) * 0.5f};
-    for(int a = 0; a < 3; ++a)
+    uint32_t childBase = 0xffffffffu;
+    bool     median    = false;
+    if(i < ntri)
     {
-        const uint32_t ck = fkey(c[a]);
-        atomicMin(&cb[6 * child + a], ck);
-        atomicMax(&cb[6 * child + 3 + a], ck);
-    }
-    if(r.axis < 0)
-    {
-        const float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
-        for(int a = 0; a < 3; ++a)
+        const uint32_t ni = nodeOf[i];
+        const uint32_t p  = order[i];
+        uint32_t       s  = 0xffffffffu;
+        if(ni >= levelStart) s = splitOf[ni - levelStart];
+        if(s == 0xffffffffu)
         {
-            atomicMin(&nodes[child].bmin[a], fkey(lo[a]));
-            atomicMax(&nodes[child].bmax[a], fkey(hi[a]));
+            orderOut[i]  = p;
+            nodeOfOut[i] = ni;
+        }
+        else
+        {
+            const SplitRec r     = splits[s];
+            const uint32_t start = nodes[r.child].first;
+            const uint32_t lBefore = scanL[i] - scanL[start];
+            const bool     left    = flagsIn[i] != 0u;
+            const uint32_t pos     = left ? start + lBefore : start + r.nL + ((i - start) - lBefore);
+            const uint32_t child   = left ? r.child : r.child + 1;
+            orderOut[pos]          = p;
+            nodeOfOut[pos]         = child;
+            childBase              = r.child;
+            median                 = r.axis < 0;
+            const float4 mn = pbox[2 * p], mx = pbox[2 * p + 1];
+            const float  c[3] = {(mn.x + mx.x) * 0.5f, (mn.y + mx.y) * 0.5f, (mn.z + mx.z) * 0.5f};
+            uint32_t*    ccb  = uniform ? &lcb[left ? 0 : 1][0] : cb + 6 * (size_t)child;
+            for(int a = 0; a < 3; ++a)
+            {
+                const uint32_t ck = fkey(c[a]);
+                atomicMin(&ccb[a], ck);
+                atomicMax(&ccb[3 + a], ck);
+            }
+            if(median)
+            {
+                const float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
+                for(int a = 0; a < 3; ++a)
+                {
+                    if(uniform)
+                    {
+                        atomicMin(&lcb[left ? 0 : 1][6 + a], fkey(lo[a]));
+                        atomicMax(&lcb[left ? 0 : 1][9 + a], fkey(hi[a]));
+                    }
+                    else
+                    {
+                        atomicMin(&nodes[child].bmin[a], fkey(lo[a]));
+                        atomicMax(&nodes[child].bmax[a], fkey(hi[a]));
+                    }
+                }
+            }
+        }
+    }
+    if(uniform)
+    {
+        // childBase / median are the same for every triangle of the block (one node): take them from any lane
+        __shared__ uint32_t sChild, sMedian;
+        if(threadIdx.x == 0) { sChild = 0xffffffffu; sMedian = 0u; }
+        __syncthreads();
+        if(childBase != 0xffffffffu) { sChild = childBase; sMedian = median ? 1u : 0u; }
+        __syncthreads();
+        if(sChild != 0xffffffffu && threadIdx.x < 24)
+        {
+            const uint32_t ch = sChild + threadIdx.x / 12, w = threadIdx.x % 12;
+            const uint32_t v  = lcb[threadIdx.x / 12][w];
+            const bool     isMin = (w % 6) < 3;
+            if(v != (isMin ? kKeyPosInf : kKeyNegInf))
+            {
+                if(w < 6)
+                {
+                    if(isMin) atomicMin(&cb[6 * (size_t)ch + w], v);
+                    else atomicMax(&cb[6 * (size_t)ch + w], v);
+                }
+                else if(sMedian)
+                {
+                    if(isMin) atomicMin(&nodes[ch].bmin[w - 6], v);
+                    else atomicMax(&nodes[ch].bmax[w - 9], v);
+                }
+            }
         }
     }
 }

@@ -316,7 +316,6 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
         __syncthreads();
     }
     const uint32_t count      = countIn ? *countIn : f.npix;
-    const uint32_t lane       = threadIdx.x & 63;
     __shared__ uint32_t pushLds[8];
     const bool     literal    = (flags & PRT_FLAG_LITERAL) != 0;
     const bool     rr         = (flags & PRT_FLAG_RUSSIAN_ROULETTE) != 0;
@@ -524,7 +523,7 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
 
                 // termination — :944-961
                 bool alive = true;
-                if(!(p < 0.0f || p >= 0.0f)) alive = false;
+                if(p != p) alive = false;  // isnan(p)
                 if(alive && p == 0.0f) alive = false;
                 if(alive)
                 {

@@ -347,3 +347,138 @@ def random_soup(n_tris, seed=7, extent=4.0, size=0.6):
     sc["camera"] = _lookat_pose((0.0, 0.0, extent * 2.5), (0.0, 0.0, 0.0))
     sc["light"] = {"pos": (0.0, extent * 1.5, 0.0), "dir": (0.0, -1.0, 0.0)}
     return sc
+
+
+def sponza_scale(seed=4, detail=1.0):
+    """BASELINE.json configs[3] stand-in: an atrium of Crytek-Sponza scale (~260k triangles at detail=1), every
+    surface textured (diffuse + specular + normal maps), two storeys of columns and arches, hanging drapes —
+    long thin occluders and many material switches per path, i.e. divergence-heavy secondary rays."""
+    rng = np.random.default_rng(seed)
+    q = lambda n: max(1, int(round(n * detail)))
+    tex = [
+        _value_noise_texture(rng, 256, (0.70, 0.66, 0.58), 0.6),  # 0 stone
+        _value_noise_texture(rng, 256, (0.55, 0.50, 0.45), 0.7),  # 1 floor
+        _value_noise_texture(rng, 128, (0.65, 0.15, 0.12), 0.5),  # 2 drape red
+        _value_noise_texture(rng, 128, (0.15, 0.25, 0.60), 0.5),  # 3 drape blue
+        _value_noise_texture(rng, 128, (0.85, 0.85, 0.85), 0.8),  # 4 specular map
+        _normal_map_texture(rng, 256),  # 5
+        _normal_map_texture(rng, 128),  # 6
+        _value_noise_texture(rng, 64, (0.30, 0.45, 0.20), 0.8),  # 7 plants
+    ]
+    mats = [
+        make_material((0.9, 0.9, 0.9), (0.05, 0.05, 0.05), roughness=0.8, tex=(0, -1, 5)),  # 0 stone walls
+        make_material((0.9, 0.9, 0.9), (0.25, 0.25, 0.25), roughness=0.3, tex=(1, 4, 6)),  # 1 polished floor
+        make_material((0.9, 0.9, 0.9), (0.02, 0.02, 0.02), roughness=0.9, tex=(2, -1, -1)),  # 2 drape
+        make_material((0.9, 0.9, 0.9), (0.02, 0.02, 0.02), roughness=0.9, tex=(3, -1, -1)),  # 3 drape
+        make_material((0.8, 0.8, 0.8), (0.1, 0.1, 0.1), roughness=0.6, tex=(0, 4, 5)),  # 4 columns
+        make_material((0.7, 0.6, 0.2), (0.8, 0.7, 0.3), roughness=0.12),  # 5 brass
+        make_material((0.9, 0.9, 0.9), roughness=0.95, tex=(7, -1, -1)),  # 6 plants
+        make_material((0.9, 0.9, 0.9), (0.04, 0.04, 0.04), roughness=0.05, dissolve=0.0),  # 7 glass lamps
+    ]
+    mb = MeshBuilder()
+    L, Wd, Ht = 30.0, 12.0, 14.0
+    x0, x1, z0, z1 = -L / 2, L / 2, -Wd / 2, Wd / 2
+    mb.quad_grid((x0, 0, z0), (0, 0, Wd), (L, 0, 0), q(60), q(120), 1, uv_scale=12)  # floor
+    mb.quad_grid((x0, Ht, z0), (L, 0, 0), (0, 0, Wd), q(40), q(20), 0, uv_scale=8)  # roof
+    mb.quad_grid((x0, 0, z0), (L, 0, 0), (0, Ht, 0), q(100), q(48), 0, uv_scale=10)
+    mb.quad_grid((x0, 0, z1), (0, Ht, 0), (L, 0, 0), q(48), q(100), 0, uv_scale=10)
+    mb.quad_grid((x0, 0, z0), (0, Ht, 0), (0, 0, Wd), q(48), q(40), 0, uv_scale=6)
+    mb.quad_grid((x1, 0, z0), (0, 0, Wd), (0, Ht, 0), q(40), q(48), 0, uv_scale=6)
+    # upper gallery floors along both long sides
+    for zc in (z0 + 1.5, z1 - 1.5):
+        mb.box((x0, 5.0, zc - 1.5), (x1, 5.3, zc + 1.5), 0, n=q(24))
+    # two storeys of columns with capitals, arches between them
+    for storey, (ybase, hcol) in enumerate(((0.0, 5.0), (5.3, 4.2))):
+        for zc in (z0 + 3.0, z1 - 3.0):
+            xs = np.linspace(x0 + 2.0, x1 - 2.0, 11)
+            for i, xc in enumerate(xs):
+                mb.cylinder((xc, ybase, zc), 0.32, hcol, q(40), 4, rings=q(16))
+                mb.box((xc - 0.45, ybase + hcol - 0.35, zc - 0.45), (xc + 0.45, ybase + hcol, zc + 0.45), 4, n=q(3))
+                if i + 1 < len(xs):  # arch: half torus of small segments
+                    xa, xb = xc, xs[i + 1]
+                    r = 0.5 * (xb - xa)
+                    th = np.linspace(0.0, np.pi, q(24) + 1)
+                    for t0, t1 in zip(th[:-1], th[1:]):
+                        pa = ((xa + xb) / 2 - r * np.cos(t0), ybase + hcol - 0.9 + 0.9 * np.sin(t0))
+                        pb = ((xa + xb) / 2 - r * np.cos(t1), ybase + hcol - 0.9 + 0.9 * np.sin(t1))
+                        lo = (min(pa[0], pb[0]), min(pa[1], pb[1]) - 0.12, zc - 0.25)
+                        hi = (max(pa[0], pb[0]) + 1e-3, max(pa[1], pb[1]) + 0.12, zc + 0.25)
+                        mb.box(lo, hi, 0, n=1)
+    # drapes hanging in the nave
+    for k, xc in enumerate(np.linspace(x0 + 4.0, x1 - 4.0, 6)):
+        ph = rng.uniform(0, 6.28)
+
+        def wave(S, T, ph=ph):
+            return np.stack([0.25 * np.sin(9.0 * T + ph) * S, np.zeros_like(S), 0.15 * np.sin(7.0 * S + ph)], -1)
+
+        mb.quad_grid((xc, 9.5, -2.2), (0, -6.0, 0), (0, 0, 4.4), q(70), q(60), 2 + (k & 1), uv_scale=3, displace=wave)
+    # lamps and plants
+    for xc in np.linspace(x0 + 3.0, x1 - 3.0, 8):
+        mb.sphere((xc, 4.2, 0.0), 0.22, q(32), q(16), 7)
+        mb.cylinder((xc, 4.4, 0.0), 0.02, 5.0, q(8), 5, rings=1)
+    for xc in np.linspace(x0 + 2.5, x1 - 2.5, 6):
+        for zc in (z0 + 4.4, z1 - 4.4):
+            mb.cylinder((xc, 0.0, zc), 0.3, 0.5, q(24), 5, rings=q(2))
+            for _ in range(q(30)):
+                off = rng.normal(0, 0.3, 3)
+                mb.sphere((xc + off[0], 0.9 + abs(off[1]) * 1.4, zc + off[2]), 0.09, q(12), q(6), 6)
+    sc = mb.finish(mats, tex)
+    sc["name"] = "sponza_scale"
+    sc["camera"] = _lookat_pose((x0 + 2.5, 2.2, 0.6), (x1, 5.0, -0.5))
+    sc["light"] = {"pos": (0.0, Ht - 0.5, 0.0), "dir": (0.0, -1.0, 0.0)}
+    return sc
+
+
+def san_miguel_scale(seed=5, million_tris=10.0):
+    """BASELINE.json configs[4] stand-in: a courtyard with arcades and dense vegetation of San-Miguel scale
+    (~10 M triangles by default): tens of thousands of small leaves and finely tessellated architecture."""
+    rng = np.random.default_rng(seed)
+    target = int(million_tris * 1e6)
+    mats = [
+        make_material((0.72, 0.68, 0.6), roughness=0.9),  # 0 plaster
+        make_material((0.5, 0.42, 0.36), (0.1, 0.1, 0.1), roughness=0.5),  # 1 paving
+        make_material((0.2, 0.45, 0.12), (0.05, 0.05, 0.05), roughness=0.6),  # 2 leaves
+        make_material((0.35, 0.25, 0.15), roughness=0.8),  # 3 wood
+        make_material((0.9, 0.9, 0.9), (0.04, 0.04, 0.04), roughness=0.05, dissolve=0.0),  # 4 glass
+        make_material((0.6, 0.6, 0.62), (0.7, 0.7, 0.7), roughness=0.2),  # 5 metal
+    ]
+    mb = MeshBuilder()
+    S, Ht = 24.0, 9.0
+    # architecture: ~15 % of the budget in finely tessellated planes
+    g = max(8, int(np.sqrt(target * 0.15 / (2 * 6))))
+    bump = lambda S_, T_: np.stack([np.zeros_like(S_), 0.01 * np.sin(40 * S_) * np.sin(40 * T_), np.zeros_like(S_)], -1)
+    mb.quad_grid((-S / 2, 0, -S / 2), (0, 0, S), (S, 0, 0), g, g, 1, uv_scale=16, displace=bump)
+    for (o, eu, ev) in (((-S / 2, 0, -S / 2), (S, 0, 0), (0, Ht, 0)), ((-S / 2, 0, S / 2), (0, Ht, 0), (S, 0, 0)),
+                        ((-S / 2, 0, -S / 2), (0, Ht, 0), (0, 0, S)), ((S / 2, 0, -S / 2), (0, 0, S), (0, Ht, 0))):
+        mb.quad_grid(o, eu, ev, g, g, 0, uv_scale=8)
+    mb.quad_grid((-S / 2, Ht, -S / 2), (S, 0, 0), (0, 0, S), g, g, 0)
+    for xc in np.linspace(-S / 2 + 3, S / 2 - 3, 7):
+        for zc in (-S / 2 + 3.5, S / 2 - 3.5):
+            mb.cylinder((xc, 0.0, zc), 0.3, 4.5, 96, 0, rings=64)
+    # tables, chairs: a few thousand boxes
+    for _ in range(40):
+        c = rng.uniform(-S / 2 + 5, S / 2 - 5, 2)
+        mb.box((c[0] - 0.6, 0.7, c[1] - 0.6), (c[0] + 0.6, 0.76, c[1] + 0.6), 3, n=12, rot_y=rng.uniform(0, 3.1))
+        mb.sphere((c[0], 0.9, c[1]), 0.1, 48, 24, (4, 5)[_ & 1])
+    built = sum(p.shape[0] for p in mb.P)
+    # vegetation: leaves (2 triangles each) in clusters, fills the remaining budget
+    nleaf = max(0, (target - built) // 2)
+    ntree = 60
+    centers = np.stack([rng.uniform(-S / 2 + 2, S / 2 - 2, ntree), rng.uniform(2.0, 6.5, ntree),
+                        rng.uniform(-S / 2 + 2, S / 2 - 2, ntree)], -1)
+    which = rng.integers(0, ntree, nleaf)
+    pos = centers[which] + rng.normal(0, 1.0, (nleaf, 3)) * np.array([1.2, 0.8, 1.2])
+    pos[:, 1] = np.abs(pos[:, 1])
+    u = rng.normal(0, 1, (nleaf, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    w = np.cross(u, rng.normal(0, 1, (nleaf, 3)))
+    w /= np.linalg.norm(w, axis=1, keepdims=True)
+    sz = rng.uniform(0.02, 0.05, (nleaf, 1))
+    a, b, c, d = pos - u * sz - w * sz * 0.5, pos + u * sz - w * sz * 0.5, pos + u * sz + w * sz * 0.5, pos - u * sz + w * sz * 0.5
+    tri = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)]).astype(np.float32)
+    mb.add(tri, 2)
+    sc = mb.finish(mats)
+    sc["name"] = "san_miguel_scale"
+    sc["camera"] = _lookat_pose((-S / 2 + 1.5, 1.8, -S / 2 + 1.5), (2.0, 3.0, 2.0))
+    sc["light"] = {"pos": (0.0, Ht - 0.4, 0.0), "dir": (0.0, -1.0, 0.0)}
+    return sc
