@@ -27,6 +27,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# One HIP stream per in-flight iteration + the accumulation stream + torch's own: give every one its own hardware
+# queue (the runtime's default is 4 per process; must be set before HIP initialises).
+try:
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+except ValueError:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s
 
@@ -44,6 +51,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=5)
     ap.add_argument("--detail", type=float, default=1.4, help="scene tessellation (1.4 = ~330k triangles)")
+    ap.add_argument("--scene", default="conference", choices=["conference", "sponza", "sanmiguel"],
+                    help="conference = the metric's workload (default); the others are BASELINE.json configs[3], [4]")
+    ap.add_argument("--rr", action="store_true", help="Russian roulette (configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample")
@@ -74,7 +84,13 @@ def main():
 
     W, H, K, WU = args.width, args.height, args.steps, args.warmup
     t0 = time.time()
-    scene = scenes.conference_room(seed=2, detail=args.detail)
+    if args.scene == "conference":
+        scene = scenes.conference_room(seed=2, detail=args.detail)
+    elif args.scene == "sponza":
+        scene = scenes.sponza_scale(seed=4)
+    else:
+        scene = scenes.san_miguel_scale(seed=5, million_tris=10.0)
+    light_area = 0.02 if args.scene == "conference" else 0.5
     ntri = len(scene["indices"]) // 3
     ctx = capi.Context(W, H, device=local)
     ctx.set_scene(scene)
@@ -84,11 +100,12 @@ def main():
     if rank == 0:
         log(f"[bench] scene {scene['name']}: {ntri} triangles, BVH {st.bvh_nodes} nodes depth {st.bvh_depth} "
             f"built on GPU in {st.bvh_build_ms:.1f} ms (setup {time.time() - t0:.1f} s)")
-    ubo = uniforms.make_uniforms(scene, W, H, bounces=args.bounces, spp=1024, iteration=1)
+    ubo = uniforms.make_uniforms(scene, W, H, bounces=args.bounces, spp=1024, iteration=1, light_area=light_area)
     ctx.set_uniforms(ubo)
-    ctx.set_flags(0)  # additive accumulation: required for the multi-GPU sum
+    ctx.set_flags(capi.FLAG_RUSSIAN_ROULETTE if args.rr else 0)  # additive accumulation: required for the multi-GPU sum
     if args.pipes:
         ctx.set_pipeline_depth(args.pipes)
+    in_flight = ctx.pipeline_depth()
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
     ctx.bind_accum(accum.data_ptr())
 
@@ -203,8 +220,8 @@ def main():
             crays = cit = 0
             while cit < 256 and time.perf_counter() - t1 < args.cpu_seconds:
                 cit += 1
-                u = uniforms.make_uniforms(scene, W, H, bounces=args.bounces, spp=1024, iteration=cit)
-                _, _, r = orc.render(u, W, H, 0, flags=0, threads=threads)
+                u = uniforms.make_uniforms(scene, W, H, bounces=args.bounces, spp=1024, iteration=cit, light_area=light_area)
+                _, _, r = orc.render(u, W, H, 0, flags=capi.FLAG_RUSSIAN_ROULETTE if args.rr else 0, threads=threads)
                 crays += r
             dt = time.perf_counter() - t1
             cpu_baseline = {"value": round(crays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
@@ -227,14 +244,15 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (procedural conference-scale scene, seed 2; the reference's scenes are not in its repo)",
-            "config": {"workload": f"conference-scale room, {ntri} triangles, {W}x{H}, path tracing, "
-                                   f"{args.bounces} bounces, GGX + area-light NEE, 1 spp per step",
+            "data": f"synthetic (procedural {args.scene}-scale scene; the reference's scenes are not in its repo)",
+            "config": {"workload": f"{scene['name']} ({args.scene}-scale), {ntri} triangles, {W}x{H}, path tracing, "
+                                   f"{args.bounces} bounces{' + Russian roulette' if args.rr else ''}, GGX + area-light NEE, "
+                                   f"1 spp per step",
                        "triangles": ntri, "width": W, "height": H, "bounces": args.bounces,
                        "iterations_per_gpu": K, "parallelism": f"spp-sharded x{n_gpus}" if n_gpus > 1 else "single GPU",
                        "rays_total": int(total_rays), "rays_per_sample": round(total_rays / (K * n_gpus * W * H), 3),
                        "bvh_build_ms": round(st.bvh_build_ms, 2), "image_finite": finite,
-                       "iterations_in_flight": args.pipes or 4},
+                       "iterations_in_flight": in_flight, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "kernels": kernels,

@@ -124,9 +124,11 @@ int prt_render_iteration(prt_context* ctx, int mode);
  * stride = world size). */
 int prt_render(prt_context* ctx, int mode, uint32_t first_iter, uint32_t n_iter, uint32_t iter_stride);
 /* Iterations of the path mode are independent until their radiance terms are added to the image, so up to
- * `n` of them (1..8, default 4) are in flight on separate HIP streams; the sums are still formed in iteration
+ * `n` of them (1..8) are in flight on separate HIP streams; the sums are still formed in iteration
  * order (bit-identical to n = 1). No counterpart in the reference (one queue, one frame at a time). */
 int prt_set_pipeline_depth(prt_context* ctx, int n);
+int prt_get_pipeline_depth(const prt_context* ctx); /* current depth (default: 3 when the process has >= 8 HIP
+                                                       hardware queues, GPU_MAX_HW_QUEUES, else 2) */
 /* vkQueueWaitIdle — vkTools.cpp:212 */
 int prt_sync(prt_context* ctx);
 

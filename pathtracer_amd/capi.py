@@ -22,7 +22,7 @@ EXPORTS = [
     "prt_upload_scrambles", "prt_set_uniforms", "prt_set_flags", "prt_render_iteration", "prt_render", "prt_sync",
     "prt_clear_accum", "prt_read_accum", "prt_device_accum_ptr", "prt_bind_accum", "prt_postprocess",
     "prt_read_hit_ids", "prt_get_stats", "prt_reset_stats", "prt_trace", "prt_trace_device", "prt_read_bvh",
-    "prt_read_sobol", "prt_set_profiling", "prt_get_profile", "prt_set_pipeline_depth",
+    "prt_read_sobol", "prt_set_profiling", "prt_get_profile", "prt_set_pipeline_depth", "prt_get_pipeline_depth",
 ]
 
 K_GENERATE, K_EXTEND, K_SHADE, K_SHADOW, K_AO_SHADE, K_RESOLVE, K_COUNT = 0, 1, 2, 3, 4, 5, 8
@@ -88,6 +88,7 @@ def lib():
         L.prt_set_profiling.argtypes = [vp, i32]
         L.prt_get_profile.argtypes = [vp, C.POINTER(Profile)]
         L.prt_set_pipeline_depth.argtypes = [vp, i32]
+        L.prt_get_pipeline_depth.argtypes = [vp]
         for name in EXPORTS:
             if name != "prt_last_error":
                 getattr(L, name).restype = i32
@@ -178,6 +179,9 @@ class Context:
 
     def set_pipeline_depth(self, n):
         self._chk(self.L.prt_set_pipeline_depth(self.h_, n))
+
+    def pipeline_depth(self):
+        return int(self.L.prt_get_pipeline_depth(self.h_))
 
     def clear_accum(self):
         self._chk(self.L.prt_clear_accum(self.h_))

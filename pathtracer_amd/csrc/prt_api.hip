@@ -80,7 +80,7 @@ struct prt_context
     prt_uniforms        ubo{};
     float4 *            accumOwn = nullptr, *accum = nullptr;
     Pipe                pipes[kMaxPipes];
-    int                 nPipes   = 4;   // passes in flight (prt_set_pipeline_depth)
+    int                 nPipes   = 2;   // passes in flight (prt_set_pipeline_depth)
     int                 nextPipe = 0, lastPipe = 0;
     int                 lastMode = -1;
     bool                lastPipelined = false;
@@ -297,6 +297,9 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
     }
     if(e == hipSuccess) e = hipMemset(c->accumOwn, 0, n * sizeof(float4));
     if(e == hipSuccess) e = hipMemset(c->stats, 0, kStatWords * sizeof(unsigned long long));
+    // each pipe wants a hardware queue of its own next to the main stream (and the host application's streams)
+    if(const char* qe = getenv("GPU_MAX_HW_QUEUES"))
+        if(atoi(qe) >= 8) c->nPipes = 3;
     if(const char* pe = getenv("PRT_PIPES"))
     {
         const int np = atoi(pe);
@@ -839,6 +842,8 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
     }
     return PRT_OK;
 }
+
+int prt_get_pipeline_depth(const prt_context* c) { return c ? c->nPipes : PRT_E_INVALID; }
 
 int prt_set_pipeline_depth(prt_context* c, int n)
 {
