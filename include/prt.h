@@ -81,6 +81,13 @@ typedef struct prt_stats
 #define PRT_K_RESOLVE 5  /* E += terms of the pass, in path order (pathRT.rgen:939-942, :973) */
 #define PRT_K_COUNT 8
 
+/* Wave-level work of the traversal kernels at profiling level 2: number of wave-wide node steps / triangle tests /
+ * ray set-ups executed, and the lanes that did useful work in them (lanes / (64 * steps) = SIMD utilisation). */
+typedef struct prt_wave_steps
+{
+    uint64_t node_steps, node_lanes, tri_steps, tri_lanes, setup_steps, setup_lanes;
+} prt_wave_steps;
+
 typedef struct prt_profile
 {
     double   ms[PRT_K_COUNT];       /* summed kernel time per kind, HIP events on the context's stream */
@@ -88,6 +95,7 @@ typedef struct prt_profile
     uint64_t closest_rays, any_rays;
     uint64_t closest_nodes, closest_tris; /* 64-byte nodes fetched / triangles tested by closest-hit rays */
     uint64_t any_nodes, any_tris;         /* ... by any-hit rays (both only at profiling level 2) */
+    prt_wave_steps closest_steps, any_steps;
 } prt_profile;
 
 /* VkRTX::VkRTX(ctx, extent) — vkRTX_setup.h:20-24. Binds to HIP device `device_ordinal`. */

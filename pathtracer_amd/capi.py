@@ -35,10 +35,16 @@ class Stats(C.Structure):
                 ("bvh_inner_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("bvh_build_ms", C.c_float)]
 
 
+class WaveSteps(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("node_steps", "node_lanes", "tri_steps", "tri_lanes", "setup_steps",
+                                          "setup_lanes")]
+
+
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8), ("closest_rays", C.c_uint64),
                 ("any_rays", C.c_uint64), ("closest_nodes", C.c_uint64), ("closest_tris", C.c_uint64),
-                ("any_nodes", C.c_uint64), ("any_tris", C.c_uint64)]
+                ("any_nodes", C.c_uint64), ("any_tris", C.c_uint64), ("closest_steps", WaveSteps),
+                ("any_steps", WaveSteps)]
 
 
 class _Tex(C.Structure):

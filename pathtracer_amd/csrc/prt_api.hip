@@ -20,7 +20,7 @@ using namespace prt;
 
 static std::string g_createError;
 
-static constexpr uint32_t kStatWords    = 8;
+static constexpr uint32_t kStatWords    = 20;
 static constexpr uint32_t kCounterWords = 256;
 static constexpr uint32_t kMaxBounces   = 24;  // UI cap is 10 (vkContext.cpp:266)
 static constexpr int      kMaxPipes     = 8;
@@ -982,6 +982,16 @@ int prt_get_profile(prt_context* c, prt_profile* out)
     out->closest_tris  = st[3];
     out->any_nodes     = st[4];
     out->any_tris      = st[5];
+    for(int k = 0; k < 2; ++k)
+    {
+        prt_wave_steps& w = k == 0 ? out->closest_steps : out->any_steps;
+        w.node_steps      = st[8 + 6 * k];
+        w.node_lanes      = st[9 + 6 * k];
+        w.tri_steps       = st[10 + 6 * k];
+        w.tri_lanes       = st[11 + 6 * k];
+        w.setup_steps     = st[12 + 6 * k];
+        w.setup_lanes     = st[13 + 6 * k];
+    }
     return PRT_OK;
 }
 

@@ -60,7 +60,7 @@ struct FrameView
     uint8_t*  dead;   // pixel returned early in this iteration (primary miss)
     uint8_t*  nvert;  // terms stored for the pixel in this pass | 0x40 overwrite E | 0x80 reset E first
     unsigned long long* stats;  // [0] closest-hit rays, [1] any-hit rays, [2..3] nodes / triangles visited by
-                                // closest-hit rays, [4..5] by any-hit rays (profiling level 2 only)
+                                // closest-hit rays, [4..5] by any-hit rays, [8..13] / [14..19] wave-step utilisation (profiling level 2 only)
 };
 
 PRT_DEV uint32_t wave_push(bool pred, uint32_t* counter)
@@ -137,6 +137,13 @@ PRT_DEV void flush_counts(const FrameView& f, uint32_t queued, uint32_t skippedL
         {
             atomicAdd(f.stats + 2 + 2 * kind, (unsigned long long)n);
             atomicAdd(f.stats + 3 + 2 * kind, (unsigned long long)t);
+            unsigned long long* u = f.stats + 8 + 6 * kind;
+            atomicAdd(u + 0, (unsigned long long)tc.wNode);
+            atomicAdd(u + 1, (unsigned long long)tc.lNode);
+            atomicAdd(u + 2, (unsigned long long)tc.wTri);
+            atomicAdd(u + 3, (unsigned long long)tc.lTri);
+            atomicAdd(u + 4, (unsigned long long)tc.wSetup);
+            atomicAdd(u + 5, (unsigned long long)tc.lSetup);
         }
     }
 }
@@ -235,7 +242,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_extend(Sce
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     const uint32_t      count = countPtr ? *countPtr : f.npix;
     uint32_t            nskip = 0;
-    TraceCount          tc    = {0u, 0u};
+    TraceCount          tc    = {};
     ExtendIO            io{f, queue, primary};
     trace_stream<false, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nskip, tc);
     flush_counts<INSTR>(f, count, nskip, tc, 0);
@@ -592,7 +599,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_shadow(Sce
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     const uint32_t      count = *countPtr;
     uint32_t            nskip = 0;
-    TraceCount          tc    = {0u, 0u};
+    TraceCount          tc    = {};
     ShadowIO            io{f, queue, f.contrib + (size_t)bounce * f.npix};
     trace_stream<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nskip, tc);
     flush_counts<INSTR>(f, count, nskip, tc, 1);
@@ -763,7 +770,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_trace_batc
 {
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     uint32_t            nskip = 0;
-    TraceCount          tc    = {0u, 0u};
+    TraceCount          tc    = {};
     BatchIO             io{rays, hits};
     trace_stream<ANY, false>(bvh, &stackLds[threadIdx.x], n, workCtr, tune, io, nskip, tc);
 }

@@ -64,6 +64,9 @@ struct Hit
 struct TraceCount
 {
     uint32_t nodes, tris;
+    // wave-level step counts (lane 0 only): how many lanes worked in each wave-wide node step / triangle step / ray
+    // set-up, for the SIMD-utilisation figures of prt_get_profile
+    uint32_t wNode, lNode, wTri, lTri, wSetup, lSetup;
 };
 
 // traversal knobs (wave-uniform kernel argument)
@@ -343,7 +346,7 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, f3 o, float tmin, f3 d,
     RayCtx r;
     ray_prepare(bvh, o, tmin, d, tmax, r);
     Hit        best = hit_none(tmax);
-    TraceCount tc   = {0u, 0u};
+    TraceCount tc   = {};
     int32_t    spill[PRT_SPILL_STACK];
     PRT_STACK_AT(lds, 0) = (uint32_t)kSentinel;
     int     sp  = 1;
@@ -409,6 +412,11 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
             const uint32_t avail = chunkEnd - chunkPos;
             const uint32_t take  = nIdle < avail ? nIdle : avail;
             const uint32_t rank  = (uint32_t)__popcll(idleMask & ltMask);
+            if(INSTR && lane == 0 && take)
+            {
+                tc.wSetup++;
+                tc.lSetup += take;
+            }
             if(!active && rank < take)
             {
                 f3    o, d;
@@ -434,6 +442,15 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
         //      it and keeps descending; lanes at a second leaf (or finished) wait
         for(;;)
         {
+            if(INSTR)
+            {
+                const uint32_t n = (uint32_t)__popcll(__ballot(active && (uint32_t)cur < (uint32_t)kSentinel));
+                if(lane == 0 && n)
+                {
+                    tc.wNode++;
+                    tc.lNode += n;
+                }
+            }
             if(active && (uint32_t)cur < (uint32_t)kSentinel)
             {
                 if(INSTR) tc.nodes++;
@@ -458,7 +475,25 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
         {
             const uint32_t nLeaf = (uint32_t)__popcll(__ballot(active && leaf != kEmptyLeaf));
             if(nLeaf == 0 || (round > 0 && nLeaf < tune.leafMin)) break;
-            if(active && leaf != kEmptyLeaf)
+            const bool has = active && leaf != kEmptyLeaf;
+            if(INSTR)
+            {
+                // the wave runs as many sequential tests as its largest leaf; lTri counts the tests that did work
+                const uint32_t cnt = has ? (~(uint32_t)leaf & 7u) : 0u;
+                uint32_t       tot = cnt, mx = cnt;
+                for(int o = 32; o > 0; o >>= 1)
+                {
+                    tot += (uint32_t)__shfl_xor((int)tot, o, 64);
+                    const uint32_t m = (uint32_t)__shfl_xor((int)mx, o, 64);
+                    mx               = m > mx ? m : mx;
+                }
+                if(lane == 0 && tot)
+                {
+                    tc.wTri += mx;
+                    tc.lTri += tot;
+                }
+            }
+            if(has)
             {
                 const bool occluded = leaf_test<ANY, INSTR>(bvh, r, leaf, best, tc);
                 leaf                = kEmptyLeaf;

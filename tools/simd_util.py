@@ -1,0 +1,17 @@
+"""SIMD utilisation of the traversal kernels on the bench workload (profiling level 2 counters)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pathtracer_amd import capi, scenes, uniforms
+W, H = 1920, 1080
+sc = scenes.conference_room(seed=2, detail=1.4)
+ctx = capi.Context(W, H); ctx.set_scene(sc); ctx.set_seed(2); ctx.build_accel()
+ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=5, iteration=1))
+ctx.set_profiling(2); ctx.reset_stats(); ctx.render(0, 1, 2, 1)
+p = ctx.profile()
+for name, rays, nodes, tris, s in (("closest", p.closest_rays, p.closest_nodes, p.closest_tris, p.closest_steps),
+                                   ("any", p.any_rays, p.any_nodes, p.any_tris, p.any_steps)):
+    wb = rays / 64.0
+    print(f"{name}: rays {rays}  nodes/ray {nodes / rays:.2f}  tris/ray {tris / rays:.2f}")
+    print(f"   node steps/64 rays {s.node_steps / wb:.1f}  utilisation {s.node_lanes / (64.0 * s.node_steps):.3f}")
+    print(f"   tri  steps/64 rays {s.tri_steps / wb:.1f}  utilisation {s.tri_lanes / (64.0 * s.tri_steps):.3f}")
+    print(f"   setups/64 rays     {s.setup_steps / wb:.2f}  utilisation {s.setup_lanes / (64.0 * s.setup_steps):.3f}")
