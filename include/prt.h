@@ -70,6 +70,8 @@ typedef struct prt_stats
     uint32_t bvh_inner_nodes; /* 64-byte traversal nodes */
     uint32_t bvh_depth;
     float    bvh_build_ms;    /* wall time of the last prt_build_accel */
+    float    bvh_refit_ms;    /* wall time of the last prt_refit_accel */
+    uint32_t pad_;
 } prt_stats;
 
 /* Kernel kinds of prt_profile */
@@ -113,6 +115,12 @@ int prt_set_scene(prt_context* ctx, const prt_vertex* vertices, size_t n_vertice
 /* createAccelerationStructures (vkRTX_setup.cpp:391-415) -> vkCmdBuildAccelerationStructureNV
  * (vkRT_BLAS.cpp:271, vkRT_TLAS.cpp:262): binned-SAH BVH build on the GPU. Synchronous. */
 int prt_build_accel(prt_context* ctx);
+/* The "updateOnly" path of the reference's acceleration-structure helpers (vkRT_BLAS.cpp:209-290 and
+ * vkRT_TLAS.cpp:178-279 take `updateOnly`; vkRTX_setup.cpp:391-415 always passes false): replace the vertex
+ * array (same count, same indices) and refit the boxes of the existing tree to it. Rendering between the two
+ * calls is refused. Hits are the same as after a full rebuild (the trace result does not depend on the tree). */
+int prt_update_vertices(prt_context* ctx, const prt_vertex* vertices, size_t n_vertices);
+int prt_refit_accel(prt_context* ctx);
 
 /* generateNewScrambles + updateScrambleValueImage — vkRTX_setup.h:38-39, vkRTX_setup.cpp:808-911.
  * Seeded, stateless per (pixel, layer) hash evaluated in the kernels (default seed 1) ... */
@@ -144,6 +152,9 @@ int prt_sync(prt_context* ctx);
  * pixel (x,y) at y*W+x == gl_LaunchIDNV.xy; the image pathRTpostprocess.comp binding 1 reads. */
 int prt_clear_accum(prt_context* ctx);
 int prt_read_accum(prt_context* ctx, float* rgba_out); /* synchronous */
+/* Upload W*H float4 into the accumulation image: resume of a saved progressive render (the reference keeps the
+ * image only in device memory). Synchronous. */
+int prt_write_accum(prt_context* ctx, const float* rgba_in);
 int prt_device_accum_ptr(prt_context* ctx, void** dev_ptr);
 /* Render into caller-owned device memory (W*H*16 bytes, 16-byte aligned), e.g. a buffer that an RCCL
  * all-reduce will sum; NULL returns to the context's own buffer. */

@@ -23,6 +23,7 @@ EXPORTS = [
     "prt_clear_accum", "prt_read_accum", "prt_device_accum_ptr", "prt_bind_accum", "prt_postprocess",
     "prt_read_hit_ids", "prt_get_stats", "prt_reset_stats", "prt_trace", "prt_trace_device", "prt_read_bvh",
     "prt_read_sobol", "prt_set_profiling", "prt_get_profile", "prt_set_pipeline_depth", "prt_get_pipeline_depth",
+    "prt_update_vertices", "prt_refit_accel", "prt_write_accum",
 ]
 
 K_GENERATE, K_EXTEND, K_SHADE, K_SHADOW, K_AO_SHADE, K_RESOLVE, K_COUNT = 0, 1, 2, 3, 4, 5, 8
@@ -32,7 +33,8 @@ KERNEL_NAMES = {K_GENERATE: "generate", K_EXTEND: "extend", K_SHADE: "shade", K_
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("iterations", C.c_uint64), ("bvh_nodes", C.c_uint32),
-                ("bvh_inner_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("bvh_build_ms", C.c_float)]
+                ("bvh_inner_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("bvh_build_ms", C.c_float),
+                ("bvh_refit_ms", C.c_float), ("pad_", C.c_uint32)]
 
 
 class WaveSteps(C.Structure):
@@ -95,6 +97,9 @@ def lib():
         L.prt_get_profile.argtypes = [vp, C.POINTER(Profile)]
         L.prt_set_pipeline_depth.argtypes = [vp, i32]
         L.prt_get_pipeline_depth.argtypes = [vp]
+        L.prt_update_vertices.argtypes = [vp, vp, sz]
+        L.prt_refit_accel.argtypes = [vp]
+        L.prt_write_accum.argtypes = [vp, vp]
         for name in EXPORTS:
             if name != "prt_last_error":
                 getattr(L, name).restype = i32
@@ -157,6 +162,13 @@ class Context:
     def build_accel(self):
         self._chk(self.L.prt_build_accel(self.h_))
 
+    def update_vertices(self, vertices):
+        v = np.ascontiguousarray(vertices)
+        self._chk(self.L.prt_update_vertices(self.h_, _ptr(v), len(v)))
+
+    def refit_accel(self):
+        self._chk(self.L.prt_refit_accel(self.h_))
+
     def set_seed(self, seed):
         self._chk(self.L.prt_set_scramble_seed(self.h_, seed))
 
@@ -196,6 +208,11 @@ class Context:
         out = np.empty((self.h, self.w, 4), np.float32)
         self._chk(self.L.prt_read_accum(self.h_, _ptr(out)))
         return out
+
+    def write_accum(self, rgba):
+        a = np.ascontiguousarray(rgba, dtype=np.float32)
+        assert a.size == self.w * self.h * 4
+        self._chk(self.L.prt_write_accum(self.h_, _ptr(a)))
 
     def device_accum_ptr(self):
         p = C.c_void_p()

@@ -60,6 +60,7 @@ struct prt_context
     std::vector<void*> texMem;
     uint32_t      nverts = 0, ntri = 0, nmats = 0, ntex = 0;
     bool          haveScene = false, haveAccel = false;
+    bool          accelStale = false;  // vertices replaced since the last build / refit
 
     // acceleration structure
     BuildNode* dBuildNodes = nullptr;
@@ -69,7 +70,8 @@ struct prt_context
     float4*    dTris       = nullptr;
     uint32_t   nNodes = 0, nInner = 0, depth = 0;
     int32_t    root     = 0;
-    float      sceneAbs = 0.0f, buildMs = 0.0f;
+    float      sceneAbs = 0.0f, buildMs = 0.0f, refitMs = 0.0f;
+    LevelTable lt{};
 
     // sampling
     uint32_t* dSobol    = nullptr;
@@ -401,6 +403,71 @@ static int device_scan(prt_context* c, uint32_t* data, uint32_t n, uint32_t* til
     return PRT_OK;
 }
 
+// traversal layout of the current build tree: BVH4 with 16-bit boxes on the root box (see prt_bvh.hpp); shared by
+// prt_build_accel and prt_refit_accel
+static int emit_layout(prt_context* c)
+{
+    const uint32_t N = c->ntri, nNodes = c->nNodes;
+    hipStream_t    st = c->stream;
+    uint32_t *     flags = nullptr, *tileSums = nullptr, *total = nullptr;
+    auto           cleanup = [&]() { dfree(flags); dfree(tileSums); dfree(total); };
+#define BCHK(expr)                                                                                        \
+    do                                                                                                    \
+    {                                                                                                     \
+        hipError_t e_ = (expr);                                                                           \
+        if(e_ != hipSuccess)                                                                              \
+        {                                                                                                 \
+            cleanup();                                                                                    \
+            return fail(c, PRT_E_HIP, "acceleration structure layout: %s failed: %s", #expr, hipGetErrorString(e_)); \
+        }                                                                                                 \
+    } while(0)
+    BCHK(dalloc(flags, (size_t)nNodes));
+    BCHK(dalloc(tileSums, (size_t)cdiv((size_t)nNodes, PRT_SCAN_TILE) + 1));
+    BCHK(dalloc(total, (size_t)1));
+    int rc = PRT_OK;
+    BuildNode rootNode;
+    BCHK(hipMemcpyAsync(&rootNode, c->dBuildNodes, sizeof rootNode, hipMemcpyDeviceToHost, st));
+    BCHK(hipStreamSynchronize(st));
+    auto dec = [](uint32_t k) {
+        const uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+        float          f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    float sa = 0.0f;
+    for(int k = 0; k < 3; ++k)
+    {
+        const float lo = dec(rootNode.bmin[k]), hi = dec(rootNode.bmax[k]);
+        sa             = sa < fabsf(lo) ? fabsf(lo) : sa;
+        sa             = sa < fabsf(hi) ? fabsf(hi) : sa;
+        const float ext = hi - lo;
+        c->grid.qmin[k]   = lo;
+        c->grid.qscale[k] = ext > 0.0f ? (ext / 65535.0f) * 1.0001f : 1.0f;  // qmin + 65535*scale >= hi
+    }
+    hipLaunchKernelGGL(k_wide_flags, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, c->lt, flags);
+    rc = device_scan(c, flags, nNodes, tileSums, total);
+    if(rc) { cleanup(); return rc; }
+    uint32_t nInner = 0;
+    BCHK(hipMemcpyAsync(&nInner, total, 4, hipMemcpyDeviceToHost, st));
+    BCHK(hipStreamSynchronize(st));
+    if(nInner >= (1u << 26)) { cleanup(); return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^26 BVH4 nodes"); }
+    dfree(c->dNodes);
+    dfree(c->dTris);
+    BCHK(dalloc(c->dNodes, (size_t)(nInner ? nInner : 1) * 4));
+    BCHK(dalloc(c->dTris, (size_t)3 * N));
+    hipLaunchKernelGGL(k_emit_wide, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, c->lt, flags,
+                       c->grid, c->dNodes);
+    hipLaunchKernelGGL(k_emit_tris, dim3(cdiv(N, 256)), dim3(256), 0, st, c->dVerts, c->dIdx, c->dOrder, N, c->dTris);
+    BCHK(hipGetLastError());
+    BCHK(hipStreamSynchronize(st));
+    cleanup();
+#undef BCHK
+    c->sceneAbs = sa;
+    c->nInner   = nInner;
+    c->root     = nInner ? 0 : (int32_t) ~((0u << 3) | N);
+    return PRT_OK;
+}
+
 int prt_build_accel(prt_context* c)
 {
     if(!c) return PRT_E_INVALID;
@@ -504,49 +571,62 @@ int prt_build_accel(prt_context* c)
     if(orderCur != c->dOrder)
         BCHK(hipMemcpyAsync(c->dOrder, orderCur, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
 
-    // traversal layout: BVH4 with 16-bit boxes on the root box (see prt_bvh.hpp)
-    BuildNode rootNode;
-    BCHK(hipMemcpyAsync(&rootNode, c->dBuildNodes, sizeof rootNode, hipMemcpyDeviceToHost, st));
-    BCHK(hipStreamSynchronize(st));
-    auto dec = [](uint32_t k) {
-        const uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
-        float          f;
-        memcpy(&f, &u, 4);
-        return f;
-    };
-    float sa = 0.0f;
-    for(int k = 0; k < 3; ++k)
-    {
-        const float lo = dec(rootNode.bmin[k]), hi = dec(rootNode.bmax[k]);
-        sa             = sa < fabsf(lo) ? fabsf(lo) : sa;
-        sa             = sa < fabsf(hi) ? fabsf(hi) : sa;
-        const float ext = hi - lo;
-        c->grid.qmin[k]   = lo;
-        c->grid.qscale[k] = ext > 0.0f ? (ext / 65535.0f) * 1.0001f : 1.0f;  // qmin + 65535*scale >= hi
-    }
-    hipLaunchKernelGGL(k_wide_flags, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, lt, flags);
-    rc = device_scan(c, flags, nNodes, tileSums, total);
-    if(rc) { cleanup(); return rc; }
-    uint32_t nInner = 0;
-    BCHK(hipMemcpyAsync(&nInner, total, 4, hipMemcpyDeviceToHost, st));
-    BCHK(hipStreamSynchronize(st));
-    if(nInner >= (1u << 26)) { cleanup(); return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^26 BVH4 nodes"); }
-    BCHK(dalloc(c->dNodes, (size_t)(nInner ? nInner : 1) * 4));
-    BCHK(dalloc(c->dTris, (size_t)3 * N));
-    hipLaunchKernelGGL(k_emit_wide, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, lt, flags,
-                       c->grid, c->dNodes);
-    hipLaunchKernelGGL(k_emit_tris, dim3(cdiv(N, 256)), dim3(256), 0, st, c->dVerts, c->dIdx, c->dOrder, N, c->dTris);
     BCHK(hipGetLastError());
     BCHK(hipStreamSynchronize(st));
     cleanup();
 #undef BCHK
-    c->sceneAbs  = sa;
-    c->nNodes    = nNodes;
-    c->nInner    = nInner;
-    c->depth     = depth;
-    c->root      = nInner ? 0 : (int32_t) ~((0u << 3) | N);
-    c->haveAccel = true;
-    c->buildMs   = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->lt     = lt;
+    c->nNodes = nNodes;
+    c->depth  = depth;
+    rc        = emit_layout(c);
+    if(rc) return rc;
+    c->haveAccel  = true;
+    c->accelStale = false;
+    c->buildMs    = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PRT_OK;
+}
+
+// prt_update_vertices + prt_refit_accel: the "updateOnly" path of the reference's AS helpers
+// (vkRT_BLAS.cpp:209-290, vkRT_TLAS.cpp:178-279 take updateOnly; vkRTX_setup.cpp never sets it)
+int prt_update_vertices(prt_context* c, const prt_vertex* v, size_t nv)
+{
+    if(!c) return PRT_E_INVALID;
+    if(!c->haveScene) return fail(c, PRT_E_NOSCENE, "prt_update_vertices: no scene");
+    if(!v || nv != c->nverts)
+        return fail(c, PRT_E_INVALID, "prt_update_vertices: %zu vertices given, the scene has %u", nv, c->nverts);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, sync_all(c));
+    HIPCHK(c, hipMemcpy(c->dVerts, v, nv * sizeof(prt_vertex), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_gather_shading, dim3(cdiv(c->ntri, 256)), dim3(256), 0, c->stream, c->dVerts, c->dIdx, c->ntri,
+                       c->dShadeTris);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->accelStale = c->haveAccel;  // rendering refuses to run until prt_refit_accel or prt_build_accel
+    return PRT_OK;
+}
+
+int prt_refit_accel(prt_context* c)
+{
+    if(!c) return PRT_E_INVALID;
+    if(!c->haveAccel) return fail(c, PRT_E_NOSCENE, "prt_refit_accel: no acceleration structure to update");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, sync_all(c));
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_refit_leaves, dim3(cdiv(c->nNodes, 256)), dim3(256), 0, c->stream, c->dBuildNodes, c->nNodes,
+                       c->dVerts, c->dIdx, c->dOrder);
+    for(uint32_t l = c->lt.n; l-- > 0;)
+    {
+        const uint32_t start = c->lt.start[l];
+        const uint32_t end   = l + 1 < c->lt.n ? c->lt.start[l + 1] : c->nNodes;
+        if(end > start)
+            hipLaunchKernelGGL(k_refit_level, dim3(cdiv(end - start, 256)), dim3(256), 0, c->stream, c->dBuildNodes,
+                               start, end - start);
+    }
+    HIPCHK(c, hipGetLastError());
+    const int rc = emit_layout(c);
+    if(rc) return rc;
+    c->accelStale = false;
+    c->refitMs    = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PRT_OK;
 }
 
@@ -803,6 +883,8 @@ int prt_render_iteration(prt_context* c, int mode)
     if(!c) return PRT_E_INVALID;
     if(mode != PRT_MODE_PATH && mode != PRT_MODE_AO) return fail(c, PRT_E_INVALID, "prt_render_iteration: mode %d", mode);
     if(!c->haveAccel) return fail(c, PRT_E_NOSCENE, "prt_render_iteration: no acceleration structure");
+    if(c->accelStale)
+        return fail(c, PRT_E_NOSCENE, "prt_render_iteration: vertices changed, call prt_refit_accel or prt_build_accel");
     HIPCHK(c, hipSetDevice(c->device));
     if(mode != c->lastMode)
     {
@@ -881,6 +963,16 @@ int prt_read_accum(prt_context* c, float* out)
     return PRT_OK;
 }
 
+int prt_write_accum(prt_context* c, const float* in)
+{
+    if(!c || !in) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, sync_all(c));
+    HIPCHK(c, hipMemcpyAsync(c->accum, in, (size_t)c->npix * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PRT_OK;
+}
+
 int prt_device_accum_ptr(prt_context* c, void** p)
 {
     if(!c || !p) return PRT_E_INVALID;
@@ -935,6 +1027,8 @@ int prt_get_stats(prt_context* c, prt_stats* s)
     s->bvh_inner_nodes = c->nInner;
     s->bvh_depth       = c->depth;
     s->bvh_build_ms    = c->buildMs;
+    s->bvh_refit_ms    = c->refitMs;
+    s->pad_            = 0;
     return PRT_OK;
 }
 
@@ -999,6 +1093,7 @@ int prt_trace_device(prt_context* c, const void* rays, size_t n, int any, void* 
 {
     if(!c || !rays || !hits) return PRT_E_INVALID;
     if(!c->haveAccel) return fail(c, PRT_E_NOSCENE, "prt_trace: no acceleration structure");
+    if(c->accelStale) return fail(c, PRT_E_NOSCENE, "prt_trace: vertices changed, call prt_refit_accel or prt_build_accel");
     if(n >= (1ull << 31)) return fail(c, PRT_E_LIMIT, "prt_trace: too many rays");
     HIPCHK(c, hipSetDevice(c->device));
     if(n == 0) { if(ms) *ms = 0.0f; return PRT_OK; }

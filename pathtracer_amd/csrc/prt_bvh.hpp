@@ -705,4 +705,52 @@ __global__ void __launch_bounds__(256) k_decode_nodes(const BuildNode* __restric
     out[2 * i + 1] = make_float4(fdec(n.bmax[0]), fdec(n.bmax[1]), fdec(n.bmax[2]), __int_as_float((int)n.count));
 }
 
+// ---- refit (VkAccelerationStructure "updateOnly": vkRT_BLAS.cpp:209-290 / vkRT_TLAS.cpp:178-279 with
+// updateOnly = true): the topology and the triangle order of the last build stay, the boxes follow the moved
+// vertices. Leaves first, then one launch per level from the deepest one up (levels are contiguous).
+__global__ void __launch_bounds__(256) k_refit_leaves(BuildNode* __restrict__ nodes, uint32_t nnodes,
+                                                      const prt_vertex* __restrict__ verts,
+                                                      const uint32_t* __restrict__ idx,
+                                                      const uint32_t* __restrict__ order)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= nnodes) return;
+    const uint32_t first = nodes[i].first, count = nodes[i].count;
+    if(count == 0) return;
+    uint32_t kmn[3] = {kKeyPosInf, kKeyPosInf, kKeyPosInf}, kmx[3] = {kKeyNegInf, kKeyNegInf, kKeyNegInf};
+    for(uint32_t t = first; t < first + count; ++t)
+    {
+        const uint32_t p = order[t];
+        for(int k = 0; k < 3; ++k)
+        {
+            const float* q = verts[idx[3 * p + k]].p;
+            for(int a = 0; a < 3; ++a)
+            {
+                const uint32_t key = fkey(q[a]);
+                kmn[a]             = min(kmn[a], key);
+                kmx[a]             = max(kmx[a], key);
+            }
+        }
+    }
+    for(int a = 0; a < 3; ++a)
+    {
+        nodes[i].bmin[a] = kmn[a];
+        nodes[i].bmax[a] = kmx[a];
+    }
+}
+__global__ void __launch_bounds__(256) k_refit_level(BuildNode* __restrict__ nodes, uint32_t levelStart,
+                                                     uint32_t levelCount)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= levelCount) return;
+    const uint32_t i = levelStart + j;
+    if(nodes[i].count != 0) return;
+    const uint32_t c = nodes[i].first;
+    for(int a = 0; a < 3; ++a)
+    {
+        nodes[i].bmin[a] = min(nodes[c].bmin[a], nodes[c + 1].bmin[a]);
+        nodes[i].bmax[a] = max(nodes[c].bmax[a], nodes[c + 1].bmax[a]);
+    }
+}
+
 }  // namespace prt
