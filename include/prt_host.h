@@ -65,6 +65,36 @@ int prth_render_obj(const char* obj_path, int device, uint32_t width, uint32_t h
                     uint32_t first_iteration, uint32_t n_iterations, float* accum_out, prt_uniforms* ubo_out, char* err,
                     size_t err_len);
 
+/* One entry of the top-level structure: vkRT_TLAS.cpp:58-72 AddInstance(blas, transform, instanceID,
+ * hitGroupIndex). transform is a column-major mat4 (glm), object -> world. */
+typedef struct prth_instance
+{
+    uint32_t modelIndex;
+    float    transform[16];
+    uint32_t instanceId;
+    uint32_t hitGroupIndex;
+} prth_instance;
+/* Several models / instances flattened into one world-space model (pathtracer_amd/host/Scene.h); the reference
+ * itself wires one identity instance of models[0] (vkRTX_setup.cpp:138-186). first_triangle (optional) receives
+ * n_instances + 1 entries: gl_PrimitiveID base of every instance, then the total. */
+int prth_flatten_instances(const prth_model* const* models, size_t n_models, const prth_instance* instances,
+                           size_t n_instances, prth_model** out, uint32_t* first_triangle, char* err, size_t err_len);
+/* Same as prth_render_obj for an already loaded (or flattened) model, with a camera-captured light or an
+ * AreaLight; `resume_from` / `save_to` (optional paths) restore / store the progressive state around the n
+ * iterations (Renderer::loadCheckpoint / saveCheckpoint). Needs a GPU. */
+int prth_render_model(const prth_model* model, int device, uint32_t width, uint32_t height, const prth_settings* settings,
+                      const float eye[3], const float target[3], const float* light_pos, const float* light_dir,
+                      uint32_t first_iteration, uint32_t n_iterations, const char* resume_from, const char* save_to,
+                      float* accum_out, char* err, size_t err_len);
+
+/* Image and state files of the headless renderer (the reference only presents to a swapchain). */
+int prth_write_png(const char* path, const uint8_t* rgba, uint32_t width, uint32_t height);
+int prth_checkpoint_write(const char* path, uint32_t width, uint32_t height, uint32_t next_iteration, int32_t mode,
+                          int32_t bounces, int32_t aa_rays, const float* accum);
+/* *accum is released with prth_free. */
+int prth_checkpoint_read(const char* path, uint32_t* width, uint32_t* height, uint32_t* next_iteration, int32_t* mode,
+                         int32_t* bounces, int32_t* aa_rays, float** accum, char* err, size_t err_len);
+
 #ifdef __cplusplus
 }
 #endif

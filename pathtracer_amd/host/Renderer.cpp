@@ -66,6 +66,48 @@ void Renderer::initRaytracing(const std::vector<Model>& models)
     check(prt_build_accel(m_ctx), "prt_build_accel");
 }
 
+void Renderer::initRaytracing(const std::vector<Model>& models, const std::vector<Instance>& instances)
+{
+    const FlatScene          fs = flattenInstances(models, instances);
+    const std::vector<Model> one(1, fs.model);
+    initRaytracing(one);
+}
+
+void Renderer::updateVertices(const std::vector<VertexPNTC>& vertices)
+{
+    check(prt_update_vertices(m_ctx, vertices.data(), vertices.size()), "prt_update_vertices");
+    check(prt_refit_accel(m_ctx), "prt_refit_accel");
+}
+
+void Renderer::saveCheckpoint(const std::string& path)
+{
+    Checkpoint c;
+    c.width     = width;
+    c.height    = height;
+    c.iteration = m_settings.iteration;
+    c.mode      = m_settings.rtRenderingMode;
+    c.bounces   = m_settings.numIndicesBounces;
+    c.aaRays    = m_settings.numAArays;
+    c.accum     = readAccum();
+    if(!writeCheckpoint(path, c)) throw std::runtime_error("saveCheckpoint: cannot write " + path);
+}
+
+void Renderer::loadCheckpoint(const std::string& path)
+{
+    Checkpoint  c;
+    std::string err;
+    if(!readCheckpoint(path, c, err)) throw std::runtime_error("loadCheckpoint: " + err);
+    if(c.width != width || c.height != height)
+        throw std::runtime_error("loadCheckpoint: image is " + std::to_string(c.width) + "x" + std::to_string(c.height) +
+                                 ", renderer is " + std::to_string(width) + "x" + std::to_string(height));
+    if(c.mode != m_settings.rtRenderingMode || c.bounces != m_settings.numIndicesBounces || c.aaRays != m_settings.numAArays)
+        throw std::runtime_error("loadCheckpoint: rendering mode / bounces / AA rays differ from the saved render");
+    check(prt_write_accum(m_ctx, c.accum.data()), "prt_write_accum");
+    m_settings.iteration = c.iteration;
+    m_cameraMoved        = false;  // or the next frame would restart the accumulation
+    m_camera.setCameraMoved();
+}
+
 prt_uniforms Renderer::updateGraphicsUniforms()
 {
     // the block is filled with the light transform of the PREVIOUS frame; a pending m_moveLight captures
@@ -194,6 +236,170 @@ bool writePFM(const std::string& path, const std::vector<float>& a, uint32_t w, 
             fwrite(c, sizeof(float), 3, f);
         }
     return fclose(f) == 0;
+}
+
+
+// ---- PNG (8-bit RGBA, filter 0, stored deflate blocks: no compression, any decoder reads it) -------------------
+static uint32_t crc32_of(const uint8_t* p, size_t n, uint32_t crc)
+{
+    static uint32_t table[256];
+    if(!table[1])
+        for(uint32_t i = 0; i < 256; ++i)
+        {
+            uint32_t c = i;
+            for(int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+    crc = ~crc;
+    for(size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return ~crc;
+}
+static void put32(std::vector<uint8_t>& v, uint32_t x)
+{
+    v.push_back((uint8_t)(x >> 24));
+    v.push_back((uint8_t)(x >> 16));
+    v.push_back((uint8_t)(x >> 8));
+    v.push_back((uint8_t)x);
+}
+static bool writeChunk(FILE* f, const char type[4], const std::vector<uint8_t>& data)
+{
+    std::vector<uint8_t> head;
+    put32(head, (uint32_t)data.size());
+    head.insert(head.end(), type, type + 4);
+    uint32_t crc = crc32_of((const uint8_t*)type, 4, 0);
+    crc          = crc32_of(data.data(), data.size(), crc);
+    std::vector<uint8_t> tail;
+    put32(tail, crc);
+    return fwrite(head.data(), 1, head.size(), f) == head.size() &&
+           (data.empty() || fwrite(data.data(), 1, data.size(), f) == data.size()) &&
+           fwrite(tail.data(), 1, 4, f) == 4;
+}
+bool writePNG(const std::string& path, const std::vector<uint8_t>& rgba, uint32_t w, uint32_t h)
+{
+    if(w == 0 || h == 0 || rgba.size() < (size_t)w * h * 4) return false;
+    FILE* f = fopen(path.c_str(), "wb");
+    if(!f) return false;
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    bool                 ok     = fwrite(sig, 1, 8, f) == 8;
+    std::vector<uint8_t> ihdr;
+    put32(ihdr, w);
+    put32(ihdr, h);
+    const uint8_t rest[5] = {8, 6, 0, 0, 0};  // bit depth 8, colour type 6 (RGBA), deflate, adaptive, no interlace
+    ihdr.insert(ihdr.end(), rest, rest + 5);
+    ok = ok && writeChunk(f, "IHDR", ihdr);
+    // raw scanlines, each with filter byte 0
+    const size_t         stride = (size_t)w * 4 + 1;
+    std::vector<uint8_t> raw(stride * h);
+    for(uint32_t y = 0; y < h; ++y)
+    {
+        raw[y * stride] = 0;
+        memcpy(&raw[y * stride + 1], &rgba[(size_t)y * w * 4], (size_t)w * 4);
+    }
+    uint32_t a = 1, b = 0;  // adler32
+    for(uint8_t c : raw)
+    {
+        a = (a + c) % 65521u;
+        b = (b + a) % 65521u;
+    }
+    std::vector<uint8_t> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78);
+    z.push_back(0x01);
+    for(size_t pos = 0; pos < raw.size();)
+    {
+        const size_t n = raw.size() - pos < 65535 ? raw.size() - pos : 65535;
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xff));
+        z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xff));
+        z.push_back((uint8_t)((~n >> 8) & 0xff));
+        z.insert(z.end(), raw.begin() + (long)pos, raw.begin() + (long)(pos + n));
+        pos += n;
+    }
+    put32(z, (b << 16) | a);
+    ok = ok && writeChunk(f, "IDAT", z);
+    ok = ok && writeChunk(f, "IEND", {});
+    return (fclose(f) == 0) && ok;
+}
+
+// ---- checkpoint file: 64-byte little-endian header, then W*H float4 ------------------------------------------------
+namespace {
+struct CkptHeader
+{
+    char     magic[8];  // "PRTCKPT1"
+    uint32_t width, height, iteration;
+    int32_t  mode, bounces, aaRays;
+    uint64_t payloadBytes;
+    uint32_t payloadCrc;
+    uint32_t reserved[5];
+};
+static_assert(sizeof(CkptHeader) == 64, "checkpoint header is 64 bytes");
+}  // namespace
+
+bool writeCheckpoint(const std::string& path, const Checkpoint& c)
+{
+    if(c.accum.size() != (size_t)c.width * c.height * 4) return false;
+    CkptHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "PRTCKPT1", 8);
+    h.width        = c.width;
+    h.height       = c.height;
+    h.iteration    = c.iteration;
+    h.mode         = c.mode;
+    h.bounces      = c.bounces;
+    h.aaRays       = c.aaRays;
+    h.payloadBytes = c.accum.size() * sizeof(float);
+    h.payloadCrc   = crc32_of((const uint8_t*)c.accum.data(), (size_t)h.payloadBytes, 0);
+    FILE* f        = fopen(path.c_str(), "wb");
+    if(!f) return false;
+    const bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(c.accum.data(), 1, (size_t)h.payloadBytes, f) == h.payloadBytes;
+    return (fclose(f) == 0) && ok;
+}
+
+bool readCheckpoint(const std::string& path, Checkpoint& c, std::string& err)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if(!f)
+    {
+        err = "cannot open " + path;
+        return false;
+    }
+    CkptHeader h;
+    bool       ok = fread(&h, sizeof h, 1, f) == 1;
+    if(!ok || memcmp(h.magic, "PRTCKPT1", 8) != 0)
+    {
+        fclose(f);
+        err = path + " is not a checkpoint file";
+        return false;
+    }
+    if(h.width == 0 || h.height == 0 || h.payloadBytes != (uint64_t)h.width * h.height * 16)
+    {
+        fclose(f);
+        err = path + ": inconsistent header";
+        return false;
+    }
+    c.width     = h.width;
+    c.height    = h.height;
+    c.iteration = h.iteration;
+    c.mode      = h.mode;
+    c.bounces   = h.bounces;
+    c.aaRays    = h.aaRays;
+    c.accum.resize((size_t)h.width * h.height * 4);
+    ok = fread(c.accum.data(), 1, (size_t)h.payloadBytes, f) == h.payloadBytes;
+    uint8_t extra;
+    const bool trailing = fread(&extra, 1, 1, f) == 1;
+    fclose(f);
+    if(!ok || trailing)
+    {
+        err = path + (ok ? ": trailing bytes" : ": truncated");
+        return false;
+    }
+    if(crc32_of((const uint8_t*)c.accum.data(), (size_t)h.payloadBytes, 0) != h.payloadCrc)
+    {
+        err = path + ": checksum mismatch";
+        return false;
+    }
+    return true;
 }
 
 }  // namespace prt_host

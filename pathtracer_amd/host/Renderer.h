@@ -12,6 +12,7 @@
 #include "AreaLight.h"
 #include "CameraControls.h"
 #include "Model.h"
+#include "Scene.h"
 
 namespace prt_host {
 
@@ -45,6 +46,10 @@ public:
 
     // VkRTX::initRaytracing(gpu, models, ubo, uboMem): models[0] only (vkRTX_setup.cpp:67, 459)
     void initRaytracing(const std::vector<Model>& models);
+    // several models / instances (vkRT_TLAS.cpp:58-72 AddInstance), flattened on the host: see Scene.h
+    void initRaytracing(const std::vector<Model>& models, const std::vector<Instance>& instances);
+    // vkRT_BLAS.cpp:209-290 / vkRT_TLAS.cpp:178-279 with updateOnly = true: same topology, moved vertices
+    void updateVertices(const std::vector<VertexPNTC>& vertices);
 
     // vkContext::updateGraphicsUniforms, including its bookkeeping: the light follows the camera one frame after
     // m_moveLight was set, path mode hands out m_settings.iteration and advances it by numAArays, AO mode never
@@ -56,6 +61,12 @@ public:
     // "N samples per pixel" without the UI loop's quirks: iterations first .. first+n-1 (stride for multi-GPU
     // sample sharding), light from m_light when useAreaLight, else the captured camera transform.
     void render(uint32_t firstIteration, uint32_t n, uint32_t stride = 1);
+
+    // Progressive state on disk (the reference keeps m_rtRenderTarget and m_settings.iteration in memory only):
+    // image + iteration counter + the settings that must match for the sum to stay meaningful. loadCheckpoint
+    // throws when the image size, rendering mode, bounce count or AA ray count differ.
+    void saveCheckpoint(const std::string& path);
+    void loadCheckpoint(const std::string& path);
 
     void                 clear();
     std::vector<float>   readAccum();    // W*H*4, row-major: m_rtRenderTarget
@@ -80,5 +91,16 @@ private:
 
 bool writePPM(const std::string& path, const std::vector<uint8_t>& rgba, uint32_t w, uint32_t h);
 bool writePFM(const std::string& path, const std::vector<float>& accum, uint32_t w, uint32_t h);  // colour / w
+bool writePNG(const std::string& path, const std::vector<uint8_t>& rgba, uint32_t w, uint32_t h);  // 8-bit RGBA
+
+struct Checkpoint
+{
+    uint32_t           width = 0, height = 0;
+    uint32_t           iteration = 1;  // next iteration to render (m_settings.iteration)
+    int32_t            mode = 0, bounces = 0, aaRays = 1;
+    std::vector<float> accum;          // W*H*4
+};
+bool writeCheckpoint(const std::string& path, const Checkpoint& c);
+bool readCheckpoint(const std::string& path, Checkpoint& c, std::string& err);
 
 }  // namespace prt_host

@@ -192,6 +192,30 @@ int prth_camera_uniforms(float fov, float aspect, float zn, float zf, const floa
     return 0;
 }
 
+static void setup_view(Renderer& r, const prth_settings* settings, uint32_t w, uint32_t h, const float eye[3],
+                       const float target[3], const float* lightPos, const float* lightDir)
+{
+    r.m_settings = to_settings(settings);
+    r.m_camera.setPosition(vec3(eye[0], eye[1], eye[2]));
+    r.m_camera.initDefaults((float)w / (float)h);
+    r.m_camera.lookAtPoint(vec3(target[0], target[1], target[2]));
+    if(lightPos && lightDir)
+    {
+        // an AreaLight at lightPos whose normal (-Z axis) is lightDir, built like a look-at frame
+        const vec3 d  = normalize(vec3(lightDir[0], lightDir[1], lightDir[2]));
+        const vec3 up = std::fabs(d.y) < 0.99f ? vec3(0, 1, 0) : vec3(0, 0, -1);
+        mat3       R;
+        R[2] = -d;
+        R[0] = normalize(cross(up, R[2]));
+        R[1] = cross(R[2], R[0]);
+        r.m_light.setOrientation(R);
+        r.m_light.setPosition(vec3(lightPos[0], lightPos[1], lightPos[2]));
+        r.m_light.setSize(vec2{r.m_settings.lightSourceArea, r.m_settings.lightSourceArea});
+        r.m_light.setEmission(vec3(r.m_settings.lightE, r.m_settings.lightE, r.m_settings.lightE));
+        r.useAreaLight = true;
+    }
+}
+
 int prth_render_obj(const char* objPath, int device, uint32_t w, uint32_t h, const prth_settings* settings, const float eye[3],
                     const float target[3], const float* lightPos, const float* lightDir, uint32_t first, uint32_t n,
                     float* accumOut, prt_uniforms* uboOut, char* err, size_t errLen)
@@ -202,25 +226,7 @@ int prth_render_obj(const char* objPath, int device, uint32_t w, uint32_t h, con
         std::vector<Model> models;
         models.emplace_back(std::string(objPath));
         Renderer r(device, w, h);
-        r.m_settings = to_settings(settings);
-        r.m_camera.setPosition(vec3(eye[0], eye[1], eye[2]));
-        r.m_camera.initDefaults((float)w / (float)h);
-        r.m_camera.lookAtPoint(vec3(target[0], target[1], target[2]));
-        if(lightPos && lightDir)
-        {
-            // an AreaLight at lightPos whose normal (-Z axis) is lightDir, built like a look-at frame
-            const vec3 d  = normalize(vec3(lightDir[0], lightDir[1], lightDir[2]));
-            const vec3 up = std::fabs(d.y) < 0.99f ? vec3(0, 1, 0) : vec3(0, 0, -1);
-            mat3       R;
-            R[2] = -d;
-            R[0] = normalize(cross(up, R[2]));
-            R[1] = cross(R[2], R[0]);
-            r.m_light.setOrientation(R);
-            r.m_light.setPosition(vec3(lightPos[0], lightPos[1], lightPos[2]));
-            r.m_light.setSize(vec2{r.m_settings.lightSourceArea, r.m_settings.lightSourceArea});
-            r.m_light.setEmission(vec3(r.m_settings.lightE, r.m_settings.lightE, r.m_settings.lightE));
-            r.useAreaLight = true;
-        }
+        setup_view(r, settings, w, h, eye, target, lightPos, lightDir);
         r.initRaytracing(models);
         if(uboOut)
         {
@@ -238,6 +244,113 @@ int prth_render_obj(const char* objPath, int device, uint32_t w, uint32_t h, con
         set_err(err, errLen, e.what());
         return -2;
     }
+}
+
+int prth_flatten_instances(const prth_model* const* models, size_t nModels, const prth_instance* instances, size_t nInst,
+                           prth_model** out, uint32_t* firstTriangle, char* err, size_t errLen)
+{
+    if(!models || !instances || !out) return -1;
+    try
+    {
+        std::vector<Model> ms;
+        for(size_t i = 0; i < nModels; ++i)
+        {
+            if(!models[i]) return -1;
+            ms.push_back(models[i]->m);
+        }
+        std::vector<Instance> is(nInst);
+        for(size_t i = 0; i < nInst; ++i)
+        {
+            is[i].modelIndex = instances[i].modelIndex;
+            memcpy(&is[i].transform[0][0], instances[i].transform, 64);
+            is[i].instanceId    = instances[i].instanceId;
+            is[i].hitGroupIndex = instances[i].hitGroupIndex;
+        }
+        FlatScene fs = flattenInstances(ms, is);
+        if(firstTriangle) memcpy(firstTriangle, fs.firstTriangle.data(), fs.firstTriangle.size() * sizeof(uint32_t));
+        *out = new prth_model{std::move(fs.model)};
+        return 0;
+    }
+    catch(const std::exception& e)
+    {
+        set_err(err, errLen, e.what());
+        return -2;
+    }
+}
+
+int prth_render_model(const prth_model* model, int device, uint32_t w, uint32_t h, const prth_settings* settings,
+                      const float eye[3], const float target[3], const float* lightPos, const float* lightDir, uint32_t first,
+                      uint32_t n, const char* resumeFrom, const char* saveTo, float* accumOut, char* err, size_t errLen)
+{
+    if(!model || !eye || !target || !accumOut) return -1;
+    try
+    {
+        const std::vector<Model> models(1, model->m);
+        Renderer                 r(device, w, h);
+        setup_view(r, settings, w, h, eye, target, lightPos, lightDir);
+        r.initRaytracing(models);
+        if(resumeFrom && *resumeFrom)
+        {
+            r.loadCheckpoint(resumeFrom);
+            first = r.m_settings.iteration;
+        }
+        r.render(first, n, 1);
+        r.m_settings.iteration = first + n;  // Renderer::render hands out first, first+1, ...
+        if(saveTo && *saveTo) r.saveCheckpoint(saveTo);
+        const std::vector<float> a = r.readAccum();
+        memcpy(accumOut, a.data(), a.size() * sizeof(float));
+        return 0;
+    }
+    catch(const std::exception& e)
+    {
+        set_err(err, errLen, e.what());
+        return -2;
+    }
+}
+
+int prth_write_png(const char* path, const uint8_t* rgba, uint32_t w, uint32_t h)
+{
+    if(!path || !rgba) return -1;
+    const std::vector<uint8_t> v(rgba, rgba + (size_t)w * h * 4);
+    return writePNG(path, v, w, h) ? 0 : -2;
+}
+
+int prth_checkpoint_write(const char* path, uint32_t w, uint32_t h, uint32_t nextIteration, int32_t mode, int32_t bounces,
+                          int32_t aaRays, const float* accum)
+{
+    if(!path || !accum) return -1;
+    Checkpoint c;
+    c.width     = w;
+    c.height    = h;
+    c.iteration = nextIteration;
+    c.mode      = mode;
+    c.bounces   = bounces;
+    c.aaRays    = aaRays;
+    c.accum.assign(accum, accum + (size_t)w * h * 4);
+    return writeCheckpoint(path, c) ? 0 : -2;
+}
+
+int prth_checkpoint_read(const char* path, uint32_t* w, uint32_t* h, uint32_t* nextIteration, int32_t* mode, int32_t* bounces,
+                         int32_t* aaRays, float** accum, char* err, size_t errLen)
+{
+    if(!path || !w || !h || !accum) return -1;
+    Checkpoint  c;
+    std::string e;
+    if(!readCheckpoint(path, c, e))
+    {
+        set_err(err, errLen, e);
+        return -2;
+    }
+    *w = c.width;
+    *h = c.height;
+    if(nextIteration) *nextIteration = c.iteration;
+    if(mode) *mode = c.mode;
+    if(bounces) *bounces = c.bounces;
+    if(aaRays) *aaRays = c.aaRays;
+    *accum = (float*)malloc(c.accum.size() * sizeof(float));
+    if(!*accum) return -3;
+    memcpy(*accum, c.accum.data(), c.accum.size() * sizeof(float));
+    return 0;
 }
 
 }  // extern "C"

@@ -17,7 +17,9 @@ int main(int argc, char** argv)
         fprintf(stderr,
                 "usage: %s scene.obj [--width W] [--height H] [--mode path|ao] [--spp N] [--bounces B] [--aa N]\n"
                 "          [--eye x y z] [--target x y z] [--light x y z dx dy dz] [--light-area A] [--light-e E]\n"
-                "          [--ao-rays N] [--ao-length L] [--device D] [--out image.ppm] [--pfm image.pfm]\n",
+                "          [--ao-rays N] [--ao-length L] [--device D] [--out image.ppm] [--pfm image.pfm] [--png image.png]\n"
+                "          [--model more.obj]... [--instance MODEL x y z scale]... (default: one identity instance of model 0)\n"
+                "          [--resume state.ckpt] [--checkpoint state.ckpt]  (continue / save the progressive render)\n",
                 argv[0]);
         return 2;
     }
@@ -26,7 +28,9 @@ int main(int argc, char** argv)
     Settings    s;
     vec3        eye(0, 1, 3), target(0, 1, 0), lpos, ldir;
     bool        haveLight = false;
-    std::string out = "out.ppm", pfm;
+    std::string out = "out.ppm", pfm, png, resume, checkpoint;
+    std::vector<std::string> extraModels;
+    std::vector<Instance>    instances;
     for(int i = 2; i < argc; ++i)
     {
         auto f = [&](int k) { return (float)atof(argv[i + k]); };
@@ -53,6 +57,22 @@ int main(int argc, char** argv)
         else if(!strcmp(argv[i], "--device")) { need(1); device = atoi(argv[++i]); }
         else if(!strcmp(argv[i], "--out")) { need(1); out = argv[++i]; }
         else if(!strcmp(argv[i], "--pfm")) { need(1); pfm = argv[++i]; }
+        else if(!strcmp(argv[i], "--png")) { need(1); png = argv[++i]; }
+        else if(!strcmp(argv[i], "--resume")) { need(1); resume = argv[++i]; }
+        else if(!strcmp(argv[i], "--checkpoint")) { need(1); checkpoint = argv[++i]; }
+        else if(!strcmp(argv[i], "--model")) { need(1); extraModels.push_back(argv[++i]); }
+        else if(!strcmp(argv[i], "--instance"))
+        {
+            need(5);
+            Instance in;
+            in.modelIndex = (uint32_t)atoi(argv[i + 1]);
+            const float sc = f(5);
+            in.transform[0][0] = in.transform[1][1] = in.transform[2][2] = sc;
+            in.transform[3] = vec4(f(2), f(3), f(4), 1.0f);
+            in.instanceId = (uint32_t)instances.size();
+            instances.push_back(in);
+            i += 5;
+        }
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     try
@@ -60,6 +80,7 @@ int main(int argc, char** argv)
         std::vector<Model> models;
         models.emplace_back(std::string(argv[1]));
         if(!models[0].warnings.empty()) std::cout << models[0].warnings << "\n";
+        for(const std::string& p : extraModels) models.emplace_back(p);
         Renderer r(device, W, H);
         s.samplesPerPixel = (int)spp;
         r.m_settings      = s;
@@ -80,13 +101,39 @@ int main(int argc, char** argv)
             r.m_light.setEmission(vec3(s.lightE, s.lightE, s.lightE));
             r.useAreaLight = true;
         }
-        r.initRaytracing(models);
-        r.render(1, s.rtRenderingMode == 1 ? 1u : spp, 1);
+        size_t ntri = models[0].m_indices.size() / 3;
+        if(instances.empty() && extraModels.empty())
+            r.initRaytracing(models);
+        else
+        {
+            if(instances.empty())  // every model once, where it stands
+                for(size_t k = 0; k < models.size(); ++k)
+                {
+                    Instance in;
+                    in.modelIndex = (uint32_t)k;
+                    in.instanceId = (uint32_t)k;
+                    instances.push_back(in);
+                }
+            ntri = flattenInstances(models, instances).model.m_indices.size() / 3;
+            r.initRaytracing(models, instances);
+        }
+        uint32_t first = 1;
+        if(!resume.empty())
+        {
+            r.loadCheckpoint(resume);
+            first = r.m_settings.iteration;
+        }
+        const uint32_t n = s.rtRenderingMode == 1 ? 1u : spp;  // spp = iterations rendered by THIS run
+        r.m_settings.samplesPerPixel = (int)(first + n);
+        r.render(first, n, 1);
+        r.m_settings.iteration = first + n;
+        if(!checkpoint.empty()) r.saveCheckpoint(checkpoint);
         const prt_stats st = r.stats();
-        printf("%zu triangles, BVH %u nodes (%.1f ms), %llu rays, %llu iterations\n", models[0].m_indices.size() / 3,
-               st.bvh_nodes, st.bvh_build_ms, (unsigned long long)st.rays, (unsigned long long)st.iterations);
+        printf("%zu triangles, BVH %u nodes (%.1f ms), %llu rays, iterations %u..%u\n", ntri, st.bvh_nodes, st.bvh_build_ms,
+               (unsigned long long)st.rays, first, first + n - 1);
         if(!out.empty() && !writePPM(out, r.postprocess(), W, H)) fprintf(stderr, "cannot write %s\n", out.c_str());
         if(!pfm.empty() && !writePFM(pfm, r.readAccum(), W, H)) fprintf(stderr, "cannot write %s\n", pfm.c_str());
+        if(!png.empty() && !writePNG(png, r.postprocess(), W, H)) fprintf(stderr, "cannot write %s\n", png.c_str());
     }
     catch(const std::exception& e)
     {

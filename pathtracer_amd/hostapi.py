@@ -16,7 +16,8 @@ EXPORTS = [
     "prth_model_load", "prth_model_free", "prth_model_num_vertices", "prth_model_num_indices",
     "prth_model_num_materials", "prth_model_num_textures", "prth_model_vertices", "prth_model_indices",
     "prth_model_materials", "prth_model_texture", "prth_model_warnings", "prth_obj_dump_json", "prth_image_load",
-    "prth_free", "prth_default_settings", "prth_camera_uniforms", "prth_render_obj",
+    "prth_free", "prth_default_settings", "prth_camera_uniforms", "prth_render_obj", "prth_flatten_instances",
+    "prth_render_model", "prth_write_png", "prth_checkpoint_write", "prth_checkpoint_read",
 ]
 
 
@@ -29,6 +30,11 @@ class Settings(C.Structure):
 
 class _Tex(C.Structure):
     _fields_ = [("rgba", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class _Instance(C.Structure):
+    _fields_ = [("modelIndex", C.c_uint32), ("transform", C.c_float * 16), ("instanceId", C.c_uint32),
+                ("hitGroupIndex", C.c_uint32)]
 
 
 class HostError(RuntimeError):
@@ -67,6 +73,15 @@ def lib():
         L.prth_camera_uniforms.argtypes = [C.c_float] * 4 + [fp, C.c_float, C.c_float, C.POINTER(Settings), vp, fp]
         L.prth_render_obj.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(Settings), fp, fp, fp, fp,
                                       C.c_uint32, C.c_uint32, vp, vp, C.c_char_p, sz]
+        L.prth_flatten_instances.argtypes = [C.POINTER(vp), sz, C.POINTER(_Instance), sz, C.POINTER(vp),
+                                             C.POINTER(C.c_uint32), C.c_char_p, sz]
+        L.prth_render_model.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(Settings), fp, fp, fp, fp,
+                                        C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, vp, C.c_char_p, sz]
+        L.prth_write_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+        i32p, u32p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+        L.prth_checkpoint_write.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
+                                            C.c_int32, vp]
+        L.prth_checkpoint_read.argtypes = [C.c_char_p, u32p, u32p, u32p, i32p, i32p, i32p, C.POINTER(vp), C.c_char_p, sz]
         _LIB = L
     return _LIB
 
@@ -79,29 +94,130 @@ def default_settings(**kw):
     return s
 
 
+def _scene_of(h, name):
+    L = lib()
+    nv, ni, nm, nt = (getattr(L, "prth_model_num_" + n)(h) for n in ("vertices", "indices", "materials", "textures"))
+    v = np.frombuffer(C.string_at(L.prth_model_vertices(h), nv * 48), scenes.VERTEX_DTYPE).copy() if nv else np.zeros(0, scenes.VERTEX_DTYPE)
+    i = np.frombuffer(C.string_at(L.prth_model_indices(h), ni * 4), np.uint32).copy() if ni else np.zeros(0, np.uint32)
+    m = np.frombuffer(C.string_at(L.prth_model_materials(h), nm * 96), scenes.MATERIAL_DTYPE).copy()
+    texs, paths = [], []
+    for k in range(nt):
+        t, p = _Tex(), C.c_char_p()
+        L.prth_model_texture(h, k, C.byref(t), C.byref(p))
+        texs.append(np.frombuffer(C.string_at(t.rgba, t.width * t.height * 4), np.uint8).reshape(t.height, t.width, 4).copy())
+        paths.append(p.value.decode())
+    return {"vertices": v, "indices": i, "materials": m, "textures": texs, "texture_paths": paths,
+            "warnings": L.prth_model_warnings(h).decode(errors="replace"), "name": name}
+
+
+class ModelHandle:
+    """A live prth_model (Model of the host layer); close() releases it."""
+
+    def __init__(self, handle, name):
+        self.h, self.name = handle, name
+
+    def scene(self):
+        return _scene_of(self.h, self.name)
+
+    def close(self):
+        if self.h:
+            lib().prth_model_free(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def open_model(obj_path):
+    h = C.c_void_p()
+    err = C.create_string_buffer(1024)
+    if lib().prth_model_load(os.fsencode(obj_path), C.byref(h), err, len(err)) != 0:
+        raise HostError(err.value.decode(errors="replace"))
+    return ModelHandle(h, os.path.basename(obj_path))
+
+
 def load_model(obj_path):
     """Model(path): returns a scene dict in the layout of pathtracer_amd.scenes (vertices / indices / materials /
     textures as numpy arrays) plus texture paths and loader warnings."""
+    with open_model(obj_path) as m:
+        return m.scene()
+
+
+def flatten_instances(models, instances):
+    """models: ModelHandles; instances: (modelIndex, 4x4 column-major transform as 16 floats or (4,4) array whose
+    [col][row] layout is glm's, instanceId) tuples. Returns (ModelHandle of the flattened scene, firstTriangle)."""
     L = lib()
-    h = C.c_void_p()
+    hs = (C.c_void_p * len(models))(*[m.h for m in models])
+    arr = (_Instance * max(1, len(instances)))()
+    for k, (mi, xf, iid) in enumerate(instances):
+        arr[k].modelIndex = mi
+        arr[k].transform[:] = [float(x) for x in np.asarray(xf, np.float32).reshape(16)]
+        arr[k].instanceId = iid
+    out = C.c_void_p()
+    first = (C.c_uint32 * (len(instances) + 1))()
     err = C.create_string_buffer(1024)
-    if L.prth_model_load(os.fsencode(obj_path), C.byref(h), err, len(err)) != 0:
+    if L.prth_flatten_instances(hs, len(models), arr, len(instances), C.byref(out), first, err, len(err)) != 0:
+        raise HostError(err.value.decode(errors="replace"))
+    return ModelHandle(out, "flattened"), np.array(first[:], np.uint32)
+
+
+def render_model(model, width, height, settings, eye, target, light=None, first=1, n=1, device=0, resume_from=None,
+                 save_to=None):
+    fp = C.POINTER(C.c_float)
+    a = lambda x: np.asarray(x, np.float32)
+    eye, target = a(eye), a(target)
+    lp = ld = None
+    if light is not None:
+        lp, ld = a(light[0]), a(light[1])
+    accum = np.zeros((height, width, 4), np.float32)
+    err = C.create_string_buffer(1024)
+    rc = lib().prth_render_model(model.h, device, width, height, C.byref(settings), eye.ctypes.data_as(fp),
+                                 target.ctypes.data_as(fp), lp.ctypes.data_as(fp) if lp is not None else None,
+                                 ld.ctypes.data_as(fp) if ld is not None else None, first, n,
+                                 os.fsencode(resume_from) if resume_from else None,
+                                 os.fsencode(save_to) if save_to else None, accum.ctypes.data_as(C.c_void_p), err, len(err))
+    if rc != 0:
+        raise HostError(err.value.decode(errors="replace"))
+    return accum
+
+
+def write_png(path, rgba):
+    rgba = np.ascontiguousarray(rgba, np.uint8)
+    h, w = rgba.shape[:2]
+    if lib().prth_write_png(os.fsencode(path), rgba.ctypes.data_as(C.c_void_p), w, h) != 0:
+        raise HostError(f"cannot write {path}")
+
+
+def checkpoint_write(path, accum, next_iteration, mode=0, bounces=3, aa_rays=1):
+    accum = np.ascontiguousarray(accum, np.float32)
+    h, w = accum.shape[:2]
+    if lib().prth_checkpoint_write(os.fsencode(path), w, h, next_iteration, mode, bounces, aa_rays,
+                                   accum.ctypes.data_as(C.c_void_p)) != 0:
+        raise HostError(f"cannot write {path}")
+
+
+def checkpoint_read(path):
+    w, h, it = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    mode, bounces, aa = C.c_int32(), C.c_int32(), C.c_int32()
+    p = C.c_void_p()
+    err = C.create_string_buffer(1024)
+    if lib().prth_checkpoint_read(os.fsencode(path), C.byref(w), C.byref(h), C.byref(it), C.byref(mode), C.byref(bounces),
+                                  C.byref(aa), C.byref(p), err, len(err)) != 0:
         raise HostError(err.value.decode(errors="replace"))
     try:
-        nv, ni, nm, nt = (getattr(L, "prth_model_num_" + n)(h) for n in ("vertices", "indices", "materials", "textures"))
-        v = np.frombuffer(C.string_at(L.prth_model_vertices(h), nv * 48), scenes.VERTEX_DTYPE).copy() if nv else np.zeros(0, scenes.VERTEX_DTYPE)
-        i = np.frombuffer(C.string_at(L.prth_model_indices(h), ni * 4), np.uint32).copy() if ni else np.zeros(0, np.uint32)
-        m = np.frombuffer(C.string_at(L.prth_model_materials(h), nm * 96), scenes.MATERIAL_DTYPE).copy()
-        texs, paths = [], []
-        for k in range(nt):
-            t, p = _Tex(), C.c_char_p()
-            L.prth_model_texture(h, k, C.byref(t), C.byref(p))
-            texs.append(np.frombuffer(C.string_at(t.rgba, t.width * t.height * 4), np.uint8).reshape(t.height, t.width, 4).copy())
-            paths.append(p.value.decode())
-        return {"vertices": v, "indices": i, "materials": m, "textures": texs, "texture_paths": paths,
-                "warnings": L.prth_model_warnings(h).decode(errors="replace"), "name": os.path.basename(obj_path)}
+        acc = np.frombuffer(C.string_at(p, w.value * h.value * 16), np.float32).reshape(h.value, w.value, 4).copy()
     finally:
-        L.prth_model_free(h)
+        lib().prth_free(p)
+    return {"accum": acc, "next_iteration": it.value, "mode": mode.value, "bounces": bounces.value, "aa_rays": aa.value}
 
 
 def load_image(path):

@@ -162,3 +162,123 @@ def test_undecodable_texture_falls_back_to_white(tmp_path):
     assert m["texture_paths"] == ["t.jpg", "trunc.png", "nothere.png"]  # texture options are skipped
     assert all(t.tolist() == [[[255, 255, 255, 255]]] for t in m["textures"])  # Model.cpp:352-359
     assert m["materials"][0]["normalTextureID"] == 2
+
+
+# ---- several models / instances (Scene.h; vkRT_TLAS.cpp:58-72) ---------------------------------------------------
+def _glm_mul_point(M, p):
+    """(M * vec4(p, 1)).xyz in glm's order: (m0*x + m1*y) + (m2*z + m3*1), one fp32 rounding per operation."""
+    M = np.asarray(M, np.float32).reshape(4, 4)  # M[col][row]
+    x, y, z = (p[:, k:k + 1].astype(np.float32) for k in range(3))
+    a = (M[0][None, :] * x + M[1][None, :] * y).astype(np.float32)
+    b = (M[2][None, :] * z + M[3][None, :] * np.float32(1)).astype(np.float32)
+    return (a + b).astype(np.float32)[:, :3]
+
+
+def test_flatten_instances(tmp_path):
+    (tmp_path / "b.mtl").write_text("newmtl red\nKd 1 0 0\nmap_Kd nothere.png\nnewmtl blue\nKd 0 0 1\n")
+    (tmp_path / "b.obj").write_text("mtllib b.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 -0\nvn 0 0 1\nusemtl red\nf 1//1 2//1 3//1\n"
+                                    "usemtl blue\nf 4//1 3//1 2//1\n")
+    a = hostapi.open_model(os.path.join(G, "obj", "mixed.obj"))
+    b = hostapi.open_model(str(tmp_path / "b.obj"))
+    sa, sb = a.scene(), b.scene()
+    ident = np.eye(4, dtype=np.float32)
+    # column-major: rotation about z by 90 deg, scale (2, 3, 0.5), translation (1, -2, 3)
+    M = np.zeros((4, 4), np.float32)
+    M[0] = (0, 2, 0, 0)
+    M[1] = (-3, 0, 0, 0)
+    M[2] = (0, 0, 0.5, 0)
+    M[3] = (1, -2, 3, 1)
+    flat, first = hostapi.flatten_instances([a, b], [(0, ident, 7), (1, M, 8), (1, ident, 9), (0, M, 10)])
+    fs = flat.scene()
+    na, nb = len(sa["vertices"]), len(sb["vertices"])
+    assert first.tolist() == [0, na // 3, (na + nb) // 3, (na + 2 * nb) // 3, (2 * na + 2 * nb) // 3]
+    assert (fs["indices"] == np.arange(2 * na + 2 * nb, dtype=np.uint32)).all()
+    nma, nta = len(sa["materials"]), len(sa["textures"])
+    assert len(fs["materials"]) == nma + len(sb["materials"]) and len(fs["textures"]) == nta + len(sb["textures"])
+    # merged tables: model 0 verbatim, model 1 with texture ids rebased (-1 stays -1)
+    ma, mb = fs["materials"][:nma].copy(), fs["materials"][nma:].copy()
+    ea, eb = sa["materials"].copy(), sb["materials"].copy()
+    for m in (ma, mb, ea, eb):
+        m["pad"] = 0
+    assert ma.tobytes() == ea.tobytes()
+    for f in ("diffuseTextureID", "specularTextureID", "normalTextureID"):
+        assert (mb[f] == np.where(eb[f] >= 0, eb[f] + nta, eb[f])).all()
+        mb[f] = eb[f]
+    assert mb.tobytes() == eb.tobytes()
+    assert eb["diffuseTextureID"][0] == 0 and eb["diffuseTextureID"][1] == -1
+    for t, e in zip(fs["textures"], sa["textures"] + sb["textures"]):
+        assert t.tobytes() == e.tobytes()
+    v = fs["vertices"]
+    # identity instances are bit-for-bit copies (a negative zero survives), material ids rebased
+    i0 = v[:na].copy()
+    assert i0.tobytes() == sa["vertices"].tobytes()
+    i2 = v[na + nb:na + 2 * nb].copy()
+    assert (i2["materialID"] == sb["vertices"]["materialID"] + nma).all()
+    i2["materialID"] -= nma
+    assert i2.tobytes() == sb["vertices"].tobytes()
+    assert np.signbit(sb["vertices"]["p"][3][2])
+    # transformed instances: positions bit-exact in glm's order, normals = normalize(inverse-transpose * n)
+    for sl, src, base in ((slice(na, na + nb), sb, nma), (slice(na + 2 * nb, 2 * na + 2 * nb), sa, 0)):
+        got = v[sl]
+        assert got["p"].tobytes() == _glm_mul_point(M, src["vertices"]["p"]).tobytes()
+        assert (got["materialID"] == src["vertices"]["materialID"] + base).all()
+        assert got["t"].tobytes() == src["vertices"]["t"].tobytes() and got["c"].tobytes() == src["vertices"]["c"].tobytes()
+        A = M.T[:3, :3].astype(np.float64)  # row-major linear part
+        n = src["vertices"]["n"].astype(np.float64) @ np.linalg.inv(A)  # == (inverse-transpose(A) * n) per row
+        ln = np.linalg.norm(n, axis=1, keepdims=True)
+        exp = np.where(ln > 0, n / np.where(ln > 0, ln, 1), 0)
+        ok = np.isfinite(exp).all(axis=1)
+        assert np.allclose(got["n"][ok], exp[ok], atol=2e-6)
+    with pytest.raises(hostapi.HostError):
+        hostapi.flatten_instances([a], [(3, ident, 0)])
+    with pytest.raises(hostapi.HostError):
+        hostapi.flatten_instances([a], [])
+    for m in (a, b, flat):
+        m.close()
+
+
+def test_png_writer_round_trip(tmp_path):
+    import struct
+    import zlib
+    rng = np.random.default_rng(4)
+    for (h, w) in ((1, 1), (3, 5), (130, 131), (257, 300)):  # the last two span several stored blocks
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        p = str(tmp_path / f"o{h}.png")
+        hostapi.write_png(p, img)
+        back = hostapi.load_image(p)  # the stb-equivalent decoder of the host layer
+        assert back.tobytes() == img.tobytes()
+        raw = open(p, "rb").read()  # and an independent check of the container: chunk CRCs, zlib stream
+        assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, idat = 8, b""
+        while pos < len(raw):
+            n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+            body = raw[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+            if typ == b"IHDR":
+                assert struct.unpack(">IIBBBBB", body) == (w, h, 8, 6, 0, 0, 0)
+            if typ == b"IDAT":
+                idat += body
+            pos += 12 + n
+        rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 4 + 1)
+        assert (rows[:, 0] == 0).all() and rows[:, 1:].tobytes() == img.tobytes()
+
+
+def test_checkpoint_file_round_trip(tmp_path):
+    rng = np.random.default_rng(5)
+    acc = rng.standard_normal((7, 9, 4)).astype(np.float32)
+    acc[0, 0, 0] = np.nan  # the reference's NaN pixels must survive a save / restore unchanged
+    p = str(tmp_path / "s.ckpt")
+    hostapi.checkpoint_write(p, acc, 17, mode=0, bounces=5, aa_rays=1)
+    c = hostapi.checkpoint_read(p)
+    assert c["accum"].tobytes() == acc.tobytes()
+    assert (c["next_iteration"], c["mode"], c["bounces"], c["aa_rays"]) == (17, 0, 5, 1)
+    raw = bytearray(open(p, "rb").read())
+    assert len(raw) == 64 + acc.nbytes and raw[:8] == b"PRTCKPT1"
+    bad = str(tmp_path / "bad.ckpt")
+    for mutate in (lambda r: r[:-4], lambda r: r + b"\0", lambda r: b"XRTCKPT1" + r[8:],
+                   lambda r: r[:100] + bytes([r[100] ^ 1]) + r[101:]):
+        open(bad, "wb").write(mutate(bytes(raw)))
+        with pytest.raises(hostapi.HostError):
+            hostapi.checkpoint_read(bad)
+    with pytest.raises(hostapi.HostError):
+        hostapi.checkpoint_read(str(tmp_path / "missing.ckpt"))

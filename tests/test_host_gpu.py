@@ -43,3 +43,95 @@ def test_renderer_errors_surface_as_messages(tmp_path):
     empty.write_text("v 0 0 0\n")
     with pytest.raises(hostapi.HostError):  # no triangles: prt_set_scene refuses, Renderer throws (VK_CHECK_RESULT style)
         hostapi.render_obj(str(empty), 16, 16, s, (0, 0, 1), (0, 0, 0))
+
+
+def _view_ubo(W, H, s, eye, target, light):
+    # the parameter block depends on camera / light / settings only: take it from a render of the plain model
+    _, ubo = hostapi.render_obj(os.path.join(G, "obj", "mixed.obj"), W, H, s, eye, target, light=light, first=1, n=1)
+    return ubo
+
+
+def test_instanced_scene_equals_oracle_on_flattened_arrays(po, tmp_path):
+    """Two models, four instances (Scene.h) -> one flattened model -> Renderer; oracle fed with the same arrays."""
+    (tmp_path / "quad.mtl").write_text("newmtl floor\nKd 0.7 0.7 0.6\nPr 0.4\n")
+    (tmp_path / "quad.obj").write_text("mtllib quad.mtl\nv -4 0 -4\nv 4 0 -4\nv 4 0 4\nv -4 0 4\nvn 0 1 0\nusemtl floor\n"
+                                       "f 1//1 3//1 2//1\nf 1//1 4//1 3//1\n")
+    a = hostapi.open_model(os.path.join(G, "obj", "mixed.obj"))
+    q = hostapi.open_model(str(tmp_path / "quad.obj"))
+    ident = np.eye(4, dtype=np.float32)
+
+    def xf(tx, ty, tz, sc, rot=0.0):
+        c, s_ = np.float32(np.cos(rot)), np.float32(np.sin(rot))
+        M = np.zeros((4, 4), np.float32)
+        M[0] = (c * sc, 0, -s_ * sc, 0)
+        M[1] = (0, sc, 0, 0)
+        M[2] = (s_ * sc, 0, c * sc, 0)
+        M[3] = (tx, ty, tz, 1)
+        return M
+
+    flat, first = hostapi.flatten_instances([a, q], [(1, xf(0, -0.05, 0, 1.0), 0), (0, ident, 1),
+                                                     (0, xf(1.6, 0, -0.8, 0.6, 0.7), 2), (0, xf(-1.5, 0.1, -1.0, 0.8, -1.1), 3)])
+    scene = flat.scene()
+    assert first[-1] == len(scene["indices"]) // 3
+    W, H = 96, 64
+    s = hostapi.default_settings(numIndicesBounces=3, rtRenderingMode=0, lightSourceArea=0.3)
+    eye, target = (0.3, 1.6, 2.6), (0.0, 0.5, -0.5)
+    light = ((0.0, 3.0, 0.5), (0.0, -1.0, -0.1))
+    gpu = hostapi.render_model(flat, W, H, s, eye, target, light=light, first=1, n=3)
+    ubo = _view_ubo(W, H, s, eye, target, light)
+    o = po.Oracle(scene, seed=1)
+    acc = np.zeros((H, W, 4), np.float32)
+    ids = None
+    for it in (1, 2, 3):
+        u = ubo.copy()
+        u["iteration"] = it
+        acc, ids, _ = o.render(u, W, H, 0, accum=acc, want_ids=True)
+    hit = ids[ids != 0xFFFFFFFF]
+    inst = np.searchsorted(first, hit, side="right") - 1
+    assert set(np.unique(inst).tolist()) == {0, 1, 2, 3}  # every instance is in view
+    nan = np.isnan(gpu)
+    assert (nan == np.isnan(acc)).all()
+    assert np.where(nan, 0, gpu).tobytes() == np.where(nan, 0, acc).tobytes()
+    for m in (a, q, flat):
+        m.close()
+
+
+def test_checkpoint_resume_is_bit_exact(tmp_path):
+    m = hostapi.open_model(os.path.join(G, "obj", "mixed.obj"))
+    W, H = 64, 48
+    s = hostapi.default_settings(numIndicesBounces=3)
+    eye, target = (0.2, 1.1, 0.9), (0.0, 0.6, -0.4)
+    full = hostapi.render_model(m, W, H, s, eye, target, first=1, n=6)
+    ck = str(tmp_path / "half.ckpt")
+    half = hostapi.render_model(m, W, H, s, eye, target, first=1, n=3, save_to=ck)
+    c = hostapi.checkpoint_read(ck)
+    assert c["next_iteration"] == 4 and c["bounces"] == 3
+    assert np.where(np.isnan(half), 0, half).tobytes() == np.where(np.isnan(c["accum"]), 0, c["accum"]).tobytes()
+    rest = hostapi.render_model(m, W, H, s, eye, target, first=99, n=3, resume_from=ck)  # `first` comes from the file
+    assert (np.isnan(rest) == np.isnan(full)).all()
+    assert np.where(np.isnan(rest), 0, rest).tobytes() == np.where(np.isnan(full), 0, full).tobytes()
+    with pytest.raises(hostapi.HostError):  # other image size
+        hostapi.render_model(m, W, H + 1, s, eye, target, n=1, resume_from=ck)
+    s2 = hostapi.default_settings(numIndicesBounces=4)
+    with pytest.raises(hostapi.HostError):  # other bounce count
+        hostapi.render_model(m, W, H, s2, eye, target, n=1, resume_from=ck)
+    m.close()
+
+
+def test_cli_resume_and_png(tmp_path):
+    """prt_render: 4 iterations in one run == 2 + 2 with --checkpoint / --resume; --png decodes to the --out pixels."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(hostapi.LIB_PATH), "prt_render")
+    obj = os.path.join(G, "obj", "mixed.obj")
+    common = [exe, obj, "--width", "48", "--height", "32", "--bounces", "2", "--eye", "0.2", "1.1", "0.9", "--target", "0",
+              "0.6", "-0.4"]
+    run = lambda *a: subprocess.run(common + list(a), check=True, capture_output=True, timeout=120)
+    t = lambda n: str(tmp_path / n)
+    run("--spp", "4", "--pfm", t("a.pfm"), "--out", t("a.ppm"), "--png", t("a.png"))
+    run("--spp", "2", "--checkpoint", t("s.ckpt"), "--out", t("b0.ppm"))
+    run("--spp", "2", "--resume", t("s.ckpt"), "--pfm", t("b.pfm"), "--out", t("b.ppm"))
+    assert open(t("a.pfm"), "rb").read() == open(t("b.pfm"), "rb").read()
+    ppm = open(t("a.ppm"), "rb").read()
+    px = np.frombuffer(ppm[ppm.index(b"255\n") + 4:], np.uint8).reshape(32, 48, 3)
+    png = hostapi.load_image(t("a.png"))
+    assert (png[..., :3] == px).all()
