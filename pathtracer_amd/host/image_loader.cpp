@@ -6,8 +6,8 @@
 //   grey -> (g,g,g,255), grey+alpha -> (g,g,g,a), RGB -> (r,g,b,255); 16-bit samples keep their high byte;
 //   1/2/4-bit grey scales to 0..255; PNG tRNS becomes alpha; TGA 15/16-bit is 5-5-5; BMP 32-bit with an
 //   all-zero alpha channel is opaque.
-// JPEG, GIF, PSD, HDR, PIC are not decoded: load_image() fails and the caller falls back to the 1x1 white
-// texture exactly as the reference does for a file it cannot read (Model.cpp:352-359).
+// JPEG lives in jpeg_loader.cpp. GIF, PSD, HDR, PIC are not decoded: load_image() fails and the caller falls back
+// to the 1x1 white texture exactly as the reference does for a file it cannot read (Model.cpp:352-359).
 #include "image_loader.h"
 
 #include <cstdio>
@@ -633,10 +633,10 @@ bool load_pnm(const std::vector<uint8_t>& f, Image& img)
 
 bool load_image_memory(const std::vector<uint8_t>& f, Image& img)
 {
+    if(is_jpeg(f)) return load_jpeg(f, img);  // the reference's decoder tries JPEG first
     if(f.size() >= 8 && f[0] == 137 && f[1] == 'P') return load_png(f, img);
     if(f.size() >= 2 && f[0] == 'B' && f[1] == 'M') return load_bmp(f, img);
     if(f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) return load_pnm(f, img);
-    if(f.size() >= 3 && f[0] == 0xff && f[1] == 0xd8) return false;  // JPEG: not decoded
     if(f.size() >= 4 && !memcmp(f.data(), "GIF8", 4)) return false;
     return load_tga(f, img);  // TGA has no signature: tried last
 }
