@@ -184,6 +184,35 @@ int prt_read_bvh(prt_context* ctx, prt_bvh_node* nodes_out, uint32_t* order_out)
 /* The 64 x 32 Sobol matrix words in use (sobol.h:28-33 restricted to what the path reads). */
 int prt_read_sobol(prt_context* ctx, uint32_t* words_out);
 
+/* ---- several GPUs in one process (SURVEY.md 8b "Multi-GPU", 8e) -------------------------------------------
+ * No counterpart in the reference (one VkDevice, one queue). One prt_context per listed HIP device, one host
+ * thread per member while rendering; iterations are dealt out round-robin (member r of G renders first+r,
+ * first+r+G, ...: the sample sharding of SURVEY 8e) and ONE exchange step sums the members' images into the
+ * root's: RCCL ncclReduce over xGMI when the devices are distinct (librccl.so is loaded at that moment), peer
+ * copies + an add kernel when a device is listed twice or PRT_GROUP_NO_RCCL=1. After prt_group_reduce the root
+ * holds the total and the other members' images are cleared, so render / reduce can be repeated.
+ * Across G the image differs only by fp32 summation order. Use the default additive miss semantics. */
+typedef struct prt_group prt_group;
+int prt_group_create(int n, const int* device_ordinals, uint32_t width, uint32_t height, prt_group** out);
+int prt_group_destroy(prt_group* g);
+const char* prt_group_last_error(const prt_group* g); /* g may be NULL: last error of prt_group_create */
+int prt_group_size(const prt_group* g);
+int prt_group_uses_rccl(const prt_group* g);
+prt_context* prt_group_context(prt_group* g, int member); /* for per-member calls (profiling, inspection) */
+/* prt_set_scene + prt_build_accel on every member (replicated scene and BVH) */
+int prt_group_set_scene(prt_group* g, const prt_vertex* vertices, size_t n_vertices, const uint32_t* indices,
+                        size_t n_indices, const prt_material* materials, size_t n_materials,
+                        const prt_texture* textures, size_t n_textures);
+int prt_group_set_scramble_seed(prt_group* g, uint32_t seed);
+int prt_group_set_uniforms(prt_group* g, const prt_uniforms* ubo);
+int prt_group_set_flags(prt_group* g, uint32_t flags);
+int prt_group_clear_accum(prt_group* g);
+/* iterations first_iter .. first_iter+n_iter-1, sharded over the members; returns when all have finished */
+int prt_group_render(prt_group* g, int mode, uint32_t first_iter, uint32_t n_iter);
+int prt_group_reduce(prt_group* g, int root);
+int prt_group_read_accum(prt_group* g, int root, float* rgba_out);
+int prt_group_get_stats(prt_group* g, prt_stats* out); /* rays and iterations summed over the members */
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,10 @@ EXPORTS = [
     "prt_read_hit_ids", "prt_get_stats", "prt_reset_stats", "prt_trace", "prt_trace_device", "prt_read_bvh",
     "prt_read_sobol", "prt_set_profiling", "prt_get_profile", "prt_set_pipeline_depth", "prt_get_pipeline_depth",
     "prt_update_vertices", "prt_refit_accel", "prt_write_accum",
+    "prt_group_create", "prt_group_destroy", "prt_group_last_error", "prt_group_size", "prt_group_uses_rccl",
+    "prt_group_context", "prt_group_set_scene", "prt_group_set_scramble_seed", "prt_group_set_uniforms",
+    "prt_group_set_flags", "prt_group_clear_accum", "prt_group_render", "prt_group_reduce", "prt_group_read_accum",
+    "prt_group_get_stats",
 ]
 
 K_GENERATE, K_EXTEND, K_SHADE, K_SHADOW, K_AO_SHADE, K_RESOLVE, K_COUNT = 0, 1, 2, 3, 4, 5, 8
@@ -100,8 +104,25 @@ def lib():
         L.prt_update_vertices.argtypes = [vp, vp, sz]
         L.prt_refit_accel.argtypes = [vp]
         L.prt_write_accum.argtypes = [vp, vp]
+        L.prt_group_create.argtypes = [i32, C.POINTER(i32), u32, u32, C.POINTER(vp)]
+        L.prt_group_destroy.argtypes = [vp]
+        L.prt_group_last_error.argtypes = [vp]
+        L.prt_group_last_error.restype = C.c_char_p
+        L.prt_group_size.argtypes = [vp]
+        L.prt_group_uses_rccl.argtypes = [vp]
+        L.prt_group_context.argtypes = [vp, i32]
+        L.prt_group_context.restype = vp
+        L.prt_group_set_scene.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz]
+        L.prt_group_set_scramble_seed.argtypes = [vp, u32]
+        L.prt_group_set_uniforms.argtypes = [vp, vp]
+        L.prt_group_set_flags.argtypes = [vp, u32]
+        L.prt_group_clear_accum.argtypes = [vp]
+        L.prt_group_render.argtypes = [vp, i32, u32, u32]
+        L.prt_group_reduce.argtypes = [vp, i32]
+        L.prt_group_read_accum.argtypes = [vp, i32, vp]
+        L.prt_group_get_stats.argtypes = [vp, C.POINTER(Stats)]
         for name in EXPORTS:
-            if name != "prt_last_error":
+            if name not in ("prt_last_error", "prt_group_last_error", "prt_group_context"):
                 getattr(L, name).restype = i32
         _LIB = L
     return _LIB
@@ -271,4 +292,97 @@ class Context:
     def read_sobol(self):
         out = np.zeros((64, 32), np.uint32)
         self._chk(self.L.prt_read_sobol(self.h_, _ptr(out)))
+        return out
+
+
+class Group:
+    """prt_group: several GPUs (or several contexts on one GPU) behind one handle, sample-sharded, one reduce."""
+
+    def __init__(self, ordinals, width, height):
+        self.L = lib()
+        self.w, self.h = int(width), int(height)
+        arr = (C.c_int * len(ordinals))(*ordinals)
+        h = C.c_void_p()
+        rc = self.L.prt_group_create(len(ordinals), arr, self.w, self.h, C.byref(h))
+        if rc != 0:
+            raise PrtError(f"prt_group_create: {self.L.prt_group_last_error(None).decode()} (code {rc})")
+        self.h_ = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PrtError(f"{self.L.prt_group_last_error(self.h_).decode()} (code {rc})")
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.L.prt_group_destroy(self.h_)
+            self.h_ = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return int(self.L.prt_group_size(self.h_))
+
+    def uses_rccl(self):
+        return bool(self.L.prt_group_uses_rccl(self.h_))
+
+    def set_scene(self, scene):
+        v = np.ascontiguousarray(scene["vertices"])
+        i = np.ascontiguousarray(scene["indices"], dtype=np.uint32)
+        m = np.ascontiguousarray(scene["materials"])
+        texs = [np.ascontiguousarray(t, dtype=np.uint8) for t in scene.get("textures", [])]
+        arr = (_Tex * max(1, len(texs)))()
+        for k, t in enumerate(texs):
+            arr[k].rgba = t.ctypes.data
+            arr[k].height, arr[k].width = t.shape[0], t.shape[1]
+        self._chk(self.L.prt_group_set_scene(self.h_, _ptr(v), len(v), _ptr(i), len(i), _ptr(m), len(m),
+                                             C.addressof(arr), len(texs)))
+
+    def set_seed(self, seed):
+        self._chk(self.L.prt_group_set_scramble_seed(self.h_, seed))
+
+    def set_uniforms(self, ubo):
+        ubo = np.ascontiguousarray(ubo)
+        assert ubo.nbytes == 464
+        self._chk(self.L.prt_group_set_uniforms(self.h_, _ptr(ubo)))
+
+    def set_flags(self, flags):
+        self._chk(self.L.prt_group_set_flags(self.h_, flags))
+
+    def clear_accum(self):
+        self._chk(self.L.prt_group_clear_accum(self.h_))
+
+    def render(self, mode, first_iter, n_iter):
+        self._chk(self.L.prt_group_render(self.h_, mode, first_iter, n_iter))
+
+    def reduce(self, root=0):
+        self._chk(self.L.prt_group_reduce(self.h_, root))
+
+    def read_accum(self, root=0):
+        out = np.empty((self.h, self.w, 4), np.float32)
+        self._chk(self.L.prt_group_read_accum(self.h_, root, _ptr(out)))
+        return out
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.prt_group_get_stats(self.h_, C.byref(s)))
+        return s
+
+    def member_accum(self, member):
+        """prt_read_accum on one member's context (prt_group_context)."""
+        c = self.L.prt_group_context(self.h_, member)
+        if not c:
+            raise PrtError("prt_group_context: no such member")
+        out = np.empty((self.h, self.w, 4), np.float32)
+        if self.L.prt_read_accum(C.c_void_p(c), _ptr(out)) != 0:
+            raise PrtError(self.L.prt_last_error(C.c_void_p(c)).decode())
         return out

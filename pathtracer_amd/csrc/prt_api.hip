@@ -169,9 +169,12 @@ static hipError_t pipe_alloc(Pipe& p, size_t n)
     if(e == hipSuccess) e = dalloc(p.q[1], n);
     if(e == hipSuccess) e = dalloc(p.qShadow, n);
     if(e == hipSuccess) e = dalloc(p.counters, (size_t)kCounterWords);
-    if(e == hipSuccess) e = hipMemset(p.dead, 0, n);
-    if(e == hipSuccess) e = hipMemset(p.nvert, 0, n);
-    if(e == hipSuccess) e = hipMemset(p.hitIds, 0xff, n * 4);
+    // in stream order with the pipe's kernels: hipMemset on the null stream may return before the fill has run, and
+    // a non-blocking stream does not wait for it
+    if(e == hipSuccess) e = hipMemsetAsync(p.dead, 0, n, p.stream);
+    if(e == hipSuccess) e = hipMemsetAsync(p.nvert, 0, n, p.stream);
+    if(e == hipSuccess) e = hipMemsetAsync(p.hitIds, 0xff, n * 4, p.stream);
+    if(e == hipSuccess) e = hipStreamSynchronize(p.stream);
     if(e == hipSuccess) p.allocated = true;
     return e;
 }
@@ -297,8 +300,10 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
         if(e == hipSuccess) e = dalloc(c->dSobolBytes, bytes.size());
         if(e == hipSuccess) e = hipMemcpy(c->dSobolBytes, bytes.data(), bytes.size() * 4, hipMemcpyHostToDevice);
     }
-    if(e == hipSuccess) e = hipMemset(c->accumOwn, 0, n * sizeof(float4));
-    if(e == hipSuccess) e = hipMemset(c->stats, 0, kStatWords * sizeof(unsigned long long));
+    // stream-ordered fills (see pipe_alloc), finished before the context is handed out
+    if(e == hipSuccess) e = hipMemsetAsync(c->accumOwn, 0, n * sizeof(float4), c->stream);
+    if(e == hipSuccess) e = hipMemsetAsync(c->stats, 0, kStatWords * sizeof(unsigned long long), c->stream);
+    if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
     // each pipe wants a hardware queue of its own next to the main stream (and the host application's streams)
     if(const char* qe = getenv("GPU_MAX_HW_QUEUES"))
         if(atoi(qe) >= 8) c->nPipes = 3;
@@ -1038,7 +1043,8 @@ int prt_reset_stats(prt_context* c)
     HIPCHK(c, hipSetDevice(c->device));
     prof_collect(c);
     HIPCHK(c, sync_all(c));
-    HIPCHK(c, hipMemset(c->stats, 0, kStatWords * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(c->stats, 0, kStatWords * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->iterations = 0;
     for(int k = 0; k < PRT_K_COUNT; ++k)
     {

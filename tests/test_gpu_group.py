@@ -1,0 +1,108 @@
+"""prt_group_* (include/prt.h): the single-process, several-contexts form of the sample sharding (SURVEY.md 8b
+"Multi-GPU", 8e). On the one-GPU test box both members sit on device 0, which exercises the sharding arithmetic,
+the host threads, the copy-and-add exchange and the clear-after-reduce rule; the RCCL exchange (distinct devices)
+is exercised with a one-member communicator. Bar: the reduced image equals, bit for bit, the fp32 sum of the
+members' images (root + others in member order); against an unsharded render only the summation order differs."""
+import os
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import capi, scenes, uniforms
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(sc, W, H, u, iters, seed=5):
+    c = capi.Context(W, H)
+    c.set_scene(sc)
+    c.set_seed(seed)
+    c.build_accel()
+    c.set_uniforms(u)
+    for first, n, stride in iters:
+        c.render(capi.MODE_PATH, first, n, stride)
+    out = c.read_accum()
+    rays = c.stats().rays
+    c.close()
+    return out, rays
+
+
+@pytest.mark.parametrize("members", [2, 3])
+def test_group_on_one_device_equals_member_sums(members):
+    sc = scenes.cornell_box()
+    W, H = 80, 60
+    u = uniforms.make_uniforms(sc, W, H, iteration=1, bounces=3)
+    g = capi.Group([0] * members, W, H)
+    assert g.size() == members and not g.uses_rccl()
+    g.set_scene(sc)
+    g.set_seed(5)
+    g.set_uniforms(u)
+    g.render(capi.MODE_PATH, 1, 7)  # 7 iterations over 2 or 3 members: uneven shares
+    g.reduce(0)
+    got = g.read_accum(0)
+    parts, rays = [], 0
+    for r in range(members):
+        cnt = (7 - r + members - 1) // members
+        p, n = _single(sc, W, H, u, [(1 + r, cnt, members)])
+        parts.append(p)
+        rays += n
+    exp = parts[0].copy()
+    for p in parts[1:]:
+        exp = exp + p
+    assert got.tobytes() == exp.tobytes()
+    assert g.stats().rays == rays and g.stats().iterations == 7
+    whole, _ = _single(sc, W, H, u, [(1, 7, 1)])
+    assert np.allclose(got, whole, rtol=2e-6, atol=1e-6)  # fp32 summation order only
+    # second round: the root keeps the total, the other members were cleared
+    g.render(capi.MODE_PATH, 8, 4)
+    g.reduce(0)
+    got2 = g.read_accum(0)
+    whole2, _ = _single(sc, W, H, u, [(1, 11, 1)])
+    assert np.allclose(got2, whole2, rtol=3e-6, atol=1e-6)
+    assert (got2[..., 3] == whole2[..., 3]).all()  # the sample counts are small integers: exact in any order
+    g.close()
+
+
+def test_group_reduce_to_other_root_and_errors():
+    sc = scenes.cornell_box()
+    W, H = 48, 32
+    u = uniforms.make_uniforms(sc, W, H, iteration=1, bounces=2)
+    g = capi.Group([0, 0], W, H)
+    with pytest.raises(capi.PrtError):
+        g.render(capi.MODE_PATH, 1, 2)  # no scene yet: the member's message comes through
+    g.set_scene(sc)
+    g.set_seed(5)
+    g.set_uniforms(u)
+    g.render(capi.MODE_PATH, 1, 4)
+    g.reduce(1)
+    a = g.read_accum(1)
+    assert a[..., 3].max() >= 4.0 and (g.read_accum(0) == 0).all()
+    with pytest.raises(capi.PrtError):
+        g.reduce(2)
+    g.close()
+    with pytest.raises(capi.PrtError):
+        capi.Group([], W, H)
+    with pytest.raises(capi.PrtError):
+        capi.Group([999], W, H)
+
+
+def test_group_rccl_plumbing_single_member():
+    """One member, RCCL forced: librccl.so is found, a communicator is made, ncclReduce runs in place."""
+    os.environ["PRT_GROUP_FORCE_RCCL"] = "1"
+    try:
+        sc = scenes.cornell_box()
+        W, H = 48, 32
+        u = uniforms.make_uniforms(sc, W, H, iteration=1, bounces=2)
+        g = capi.Group([0], W, H)
+        assert g.uses_rccl()
+        g.set_scene(sc)
+        g.set_seed(5)
+        g.set_uniforms(u)
+        g.render(capi.MODE_PATH, 1, 3)
+        g.reduce(0)
+        got = g.read_accum(0)
+        exp, _ = _single(sc, W, H, u, [(1, 3, 1)])
+        assert got.tobytes() == exp.tobytes()
+        g.close()
+    finally:
+        del os.environ["PRT_GROUP_FORCE_RCCL"]
