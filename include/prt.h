@@ -88,6 +88,8 @@ typedef struct prt_stats
 typedef struct prt_wave_steps
 {
     uint64_t node_steps, node_lanes, tri_steps, tri_lanes, setup_steps, setup_lanes;
+    /* s_memtime ticks summed over the waves: in ray set-up, node phases, triangle phases, whole kernel body */
+    uint64_t setup_ticks, node_ticks, tri_ticks, total_ticks;
 } prt_wave_steps;
 
 typedef struct prt_profile

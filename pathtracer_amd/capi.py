@@ -43,7 +43,7 @@ class Stats(C.Structure):
 
 class WaveSteps(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("node_steps", "node_lanes", "tri_steps", "tri_lanes", "setup_steps",
-                                          "setup_lanes")]
+                                          "setup_lanes", "setup_ticks", "node_ticks", "tri_ticks", "total_ticks")]
 
 
 class Profile(C.Structure):

@@ -20,7 +20,7 @@ using namespace prt;
 
 static std::string g_createError;
 
-static constexpr uint32_t kStatWords    = 20;
+static constexpr uint32_t kStatWords    = 28;
 static constexpr uint32_t kCounterWords = 256;
 static constexpr uint32_t kMaxBounces   = 24;  // UI cap is 10 (vkContext.cpp:266)
 static constexpr int      kMaxPipes     = 8;
@@ -1091,6 +1091,10 @@ int prt_get_profile(prt_context* c, prt_profile* out)
         w.tri_lanes       = st[11 + 6 * k];
         w.setup_steps     = st[12 + 6 * k];
         w.setup_lanes     = st[13 + 6 * k];
+        w.setup_ticks     = st[20 + 4 * k];
+        w.node_ticks      = st[21 + 4 * k];
+        w.tri_ticks       = st[22 + 4 * k];
+        w.total_ticks     = st[23 + 4 * k];
     }
     return PRT_OK;
 }

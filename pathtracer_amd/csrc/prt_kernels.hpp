@@ -60,7 +60,7 @@ struct FrameView
     uint8_t*  dead;   // pixel returned early in this iteration (primary miss)
     uint8_t*  nvert;  // terms stored for the pixel in this pass | 0x40 overwrite E | 0x80 reset E first
     unsigned long long* stats;  // [0] closest-hit rays, [1] any-hit rays, [2..3] nodes / triangles visited by
-                                // closest-hit rays, [4..5] by any-hit rays, [8..13] / [14..19] wave-step utilisation (profiling level 2 only)
+                                // closest-hit rays, [4..5] by any-hit rays, [8..13] / [14..19] wave-step utilisation, [20..23] / [24..27] phase ticks (profiling level 2 only)
 };
 
 PRT_DEV uint32_t wave_push(bool pred, uint32_t* counter)
@@ -144,6 +144,11 @@ PRT_DEV void flush_counts(const FrameView& f, uint32_t queued, uint32_t skippedL
             atomicAdd(u + 3, (unsigned long long)tc.lTri);
             atomicAdd(u + 4, (unsigned long long)tc.wSetup);
             atomicAdd(u + 5, (unsigned long long)tc.lSetup);
+            unsigned long long* y = f.stats + 20 + 4 * kind;
+            atomicAdd(y + 0, (unsigned long long)tc.cSetup);
+            atomicAdd(y + 1, (unsigned long long)tc.cNode);
+            atomicAdd(y + 2, (unsigned long long)tc.cTri);
+            atomicAdd(y + 3, (unsigned long long)tc.cTotal);
         }
     }
 }

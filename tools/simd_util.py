@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pathtracer_amd import capi, scenes, uniforms
-W, H = 1920, 1080
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 sc = scenes.conference_room(seed=2, detail=1.4)
 ctx = capi.Context(W, H); ctx.set_scene(sc); ctx.set_seed(2); ctx.build_accel()
 ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=5, iteration=1))
@@ -15,3 +15,7 @@ for name, rays, nodes, tris, s in (("closest", p.closest_rays, p.closest_nodes, 
     print(f"   node steps/64 rays {s.node_steps / wb:.1f}  utilisation {s.node_lanes / (64.0 * s.node_steps):.3f}")
     print(f"   tri  steps/64 rays {s.tri_steps / wb:.1f}  utilisation {s.tri_lanes / (64.0 * s.tri_steps):.3f}")
     print(f"   setups/64 rays     {s.setup_steps / wb:.2f}  utilisation {s.setup_lanes / (64.0 * s.setup_steps):.3f}")
+    tt = float(s.total_ticks)
+    print(f"   wave time: set-up {s.setup_ticks / tt:.3f}  node phases {s.node_ticks / tt:.3f}  triangle phases {s.tri_ticks / tt:.3f}"
+          f"   ticks per node step {s.node_ticks / s.node_steps:.0f}  per triangle step {s.tri_ticks / s.tri_steps:.0f}"
+          f"  per set-up {s.setup_ticks / s.setup_steps:.0f}")
