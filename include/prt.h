@@ -81,6 +81,7 @@ typedef struct prt_stats
 #define PRT_K_SHADOW 3   /* any-hit traversal + accumulate (pathRT.rgen:818-822, 939-942) */
 #define PRT_K_AO_SHADE 4 /* AO.rgen:222-272 */
 #define PRT_K_RESOLVE 5  /* E += terms of the pass, in path order (pathRT.rgen:939-942, :973) */
+#define PRT_K_SHADOW_EXTEND 6 /* shadow rays of bounce b and extension rays of bounce b+1 in one launch */
 #define PRT_K_COUNT 8
 
 /* Wave-level work of the traversal kernels at profiling level 2: number of wave-wide node steps / triangle tests /
@@ -147,6 +148,12 @@ int prt_render(prt_context* ctx, int mode, uint32_t first_iter, uint32_t n_iter,
 int prt_set_pipeline_depth(prt_context* ctx, int n);
 int prt_get_pipeline_depth(const prt_context* ctx); /* current depth (default: 3 when the process has >= 8 HIP
                                                        hardware queues, GPU_MAX_HW_QUEUES, else 2) */
+/* prt_render additionally puts up to `n` consecutive iterations (1..64) into ONE pass over n*W*H "pixels" when
+ * the frame is small (default: about 8 M pixels per pass, at most 8 iterations), because a launch's fixed tail does
+ * not grow with its size. Same image, bit for bit; the per-pass buffers grow n-fold. prt_render_iteration is not
+ * affected. No counterpart in the reference. */
+int prt_set_iteration_batch(prt_context* ctx, int n);
+int prt_get_iteration_batch(const prt_context* ctx);
 /* vkQueueWaitIdle — vkTools.cpp:212 */
 int prt_sync(prt_context* ctx);
 

@@ -23,16 +23,16 @@ EXPORTS = [
     "prt_clear_accum", "prt_read_accum", "prt_device_accum_ptr", "prt_bind_accum", "prt_postprocess",
     "prt_read_hit_ids", "prt_get_stats", "prt_reset_stats", "prt_trace", "prt_trace_device", "prt_read_bvh",
     "prt_read_sobol", "prt_set_profiling", "prt_get_profile", "prt_set_pipeline_depth", "prt_get_pipeline_depth",
-    "prt_update_vertices", "prt_refit_accel", "prt_write_accum",
+    "prt_update_vertices", "prt_refit_accel", "prt_write_accum", "prt_set_iteration_batch", "prt_get_iteration_batch",
     "prt_group_create", "prt_group_destroy", "prt_group_last_error", "prt_group_size", "prt_group_uses_rccl",
     "prt_group_context", "prt_group_set_scene", "prt_group_set_scramble_seed", "prt_group_set_uniforms",
     "prt_group_set_flags", "prt_group_clear_accum", "prt_group_render", "prt_group_reduce", "prt_group_read_accum",
     "prt_group_get_stats",
 ]
 
-K_GENERATE, K_EXTEND, K_SHADE, K_SHADOW, K_AO_SHADE, K_RESOLVE, K_COUNT = 0, 1, 2, 3, 4, 5, 8
+K_GENERATE, K_EXTEND, K_SHADE, K_SHADOW, K_AO_SHADE, K_RESOLVE, K_SHADOW_EXTEND, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 8
 KERNEL_NAMES = {K_GENERATE: "generate", K_EXTEND: "extend", K_SHADE: "shade", K_SHADOW: "shadow",
-                K_AO_SHADE: "ao_shade", K_RESOLVE: "resolve"}
+                K_AO_SHADE: "ao_shade", K_RESOLVE: "resolve", K_SHADOW_EXTEND: "shadow_extend"}
 
 
 class Stats(C.Structure):
@@ -101,6 +101,8 @@ def lib():
         L.prt_get_profile.argtypes = [vp, C.POINTER(Profile)]
         L.prt_set_pipeline_depth.argtypes = [vp, i32]
         L.prt_get_pipeline_depth.argtypes = [vp]
+        L.prt_set_iteration_batch.argtypes = [vp, i32]
+        L.prt_get_iteration_batch.argtypes = [vp]
         L.prt_update_vertices.argtypes = [vp, vp, sz]
         L.prt_refit_accel.argtypes = [vp]
         L.prt_write_accum.argtypes = [vp, vp]
@@ -221,6 +223,12 @@ class Context:
 
     def pipeline_depth(self):
         return int(self.L.prt_get_pipeline_depth(self.h_))
+
+    def set_iteration_batch(self, n):
+        self._chk(self.L.prt_set_iteration_batch(self.h_, n))
+
+    def iteration_batch(self):
+        return int(self.L.prt_get_iteration_batch(self.h_))
 
     def clear_accum(self):
         self._chk(self.L.prt_clear_accum(self.h_))

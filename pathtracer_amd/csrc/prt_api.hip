@@ -37,6 +37,8 @@ struct Pipe
     uint32_t * q[2] = {nullptr, nullptr}, *qShadow = nullptr;
     uint32_t*  counters   = nullptr;  // kCounterWords per pass
     uint32_t   contribCap = 0;        // path vertices the contrib buffer holds
+    size_t     cap        = 0;        // pixels (image pixels x batched iterations) the per-pixel buffers hold
+    uint32_t   lastSub    = 1;        // iterations in the pipe's last pass
     hipEvent_t evDone = nullptr, evFree = nullptr;
     bool       allocated = false, busy = false;  // busy: a resolve that frees the pipe has been enqueued
 };
@@ -48,7 +50,9 @@ struct prt_context
     uint32_t    w = 0, h = 0, npix = 0;
     uint32_t    flags = 0, seed = 1;
     int         numCU = 256;
-    uint32_t    gridExtend = 0, gridShadow = 0, gridBatch = 0, gridAo = 0;  // resident blocks of the persistent kernels
+    uint32_t    gridExtend = 0, gridShadow = 0, gridBatch = 0, gridAo = 0, gridFused = 0;
+    bool        fuse = true;  // shadow(b) + extend(b+1) in one launch (PRT_FUSE=0 turns it off)
+    uint32_t    batch = 1;    // iterations per pass in prt_render (see there)  // resident blocks of the persistent kernels
     std::string err;
 
     // scene
@@ -138,22 +142,38 @@ static void dfree(T*& p)
 }
 static inline uint32_t cdiv(size_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
+static void pipe_free_buffers(Pipe& p);
 static void pipe_free(Pipe& p)
 {
-    dfree(p.rayO); dfree(p.rayD); dfree(p.hit); dfree(p.thr); dfree(p.shO); dfree(p.shD); dfree(p.eiVis);
-    dfree(p.contrib); dfree(p.aaOff); dfree(p.hitIds); dfree(p.dead); dfree(p.nvert); dfree(p.q[0]); dfree(p.q[1]);
-    dfree(p.qShadow); dfree(p.counters);
+    pipe_free_buffers(p);
+    dfree(p.counters);
     if(p.evDone) (void)hipEventDestroy(p.evDone);
     if(p.evFree) (void)hipEventDestroy(p.evFree);
     if(p.stream) (void)hipStreamDestroy(p.stream);
     p = Pipe();
 }
+static void pipe_free_buffers(Pipe& p)
+{
+    dfree(p.rayO); dfree(p.rayD); dfree(p.hit); dfree(p.thr); dfree(p.shO); dfree(p.shD); dfree(p.eiVis);
+    dfree(p.contrib); dfree(p.aaOff); dfree(p.hitIds); dfree(p.dead); dfree(p.nvert); dfree(p.q[0]); dfree(p.q[1]);
+    dfree(p.qShadow);
+    p.contribCap = 0;
+    p.cap        = 0;
+}
+// buffers for n pixels (grows: the caller has made the pipe idle)
 static hipError_t pipe_alloc(Pipe& p, size_t n)
 {
-    if(p.allocated) return hipSuccess;
-    hipError_t e = hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking);
-    if(e == hipSuccess) e = hipEventCreateWithFlags(&p.evDone, hipEventDisableTiming);
-    if(e == hipSuccess) e = hipEventCreateWithFlags(&p.evFree, hipEventDisableTiming);
+    hipError_t e = hipSuccess;
+    if(!p.allocated)
+    {
+        e = hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking);
+        if(e == hipSuccess) e = hipEventCreateWithFlags(&p.evDone, hipEventDisableTiming);
+        if(e == hipSuccess) e = hipEventCreateWithFlags(&p.evFree, hipEventDisableTiming);
+        if(e == hipSuccess) e = dalloc(p.counters, (size_t)kCounterWords);
+        if(e == hipSuccess) p.allocated = true;
+    }
+    if(e != hipSuccess || n <= p.cap) return e;
+    pipe_free_buffers(p);
     if(e == hipSuccess) e = dalloc(p.rayO, n);
     if(e == hipSuccess) e = dalloc(p.rayD, n);
     if(e == hipSuccess) e = dalloc(p.hit, n);
@@ -168,14 +188,13 @@ static hipError_t pipe_alloc(Pipe& p, size_t n)
     if(e == hipSuccess) e = dalloc(p.q[0], n);
     if(e == hipSuccess) e = dalloc(p.q[1], n);
     if(e == hipSuccess) e = dalloc(p.qShadow, n);
-    if(e == hipSuccess) e = dalloc(p.counters, (size_t)kCounterWords);
     // in stream order with the pipe's kernels: hipMemset on the null stream may return before the fill has run, and
     // a non-blocking stream does not wait for it
     if(e == hipSuccess) e = hipMemsetAsync(p.dead, 0, n, p.stream);
     if(e == hipSuccess) e = hipMemsetAsync(p.nvert, 0, n, p.stream);
     if(e == hipSuccess) e = hipMemsetAsync(p.hitIds, 0xff, n * 4, p.stream);
     if(e == hipSuccess) e = hipStreamSynchronize(p.stream);
-    if(e == hipSuccess) p.allocated = true;
+    if(e == hipSuccess) p.cap = n;
     return e;
 }
 // every stream of the context idle
@@ -270,10 +289,23 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
         c->gridShadow = resident((const void*)k_shadow<false>);
         c->gridBatch  = resident((const void*)k_trace_batch<false>);
         c->gridAo     = resident((const void*)k_ao_shade);
+        c->gridFused  = resident((const void*)k_shadow_extend<false>);
+        if(const char* fe = getenv("PRT_FUSE")) c->fuse = atoi(fe) != 0;
+        // default batch: enough iterations to put ~8 M pixels into a pass (a 4K frame's worth), at most 8
+        {
+            const uint64_t target = 8ull << 20;
+            uint64_t       b      = (target + c->npix / 2) / c->npix;
+            c->batch              = (uint32_t)(b < 1 ? 1 : (b > 8 ? 8 : b));
+            if(const char* be = getenv("PRT_BATCH"))
+            {
+                const int v = atoi(be);
+                if(v >= 1 && v <= 64) c->batch = (uint32_t)v;
+            }
+        }
         if(const char* g = getenv("PRT_GRID_BLOCKS_PER_CU"))
         {
             const int nb = atoi(g);
-            if(nb >= 1 && nb <= 16) c->gridExtend = c->gridShadow = c->gridBatch = c->gridAo = (uint32_t)nb * (uint32_t)c->numCU;
+            if(nb >= 1 && nb <= 16) c->gridExtend = c->gridShadow = c->gridBatch = c->gridAo = c->gridFused = (uint32_t)nb * (uint32_t)c->numCU;
         }
     }
     const size_t n = c->npix;
@@ -731,7 +763,7 @@ struct ProfScope
     }
 };
 
-static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& f)
+static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& f, uint32_t nsub = 1, uint32_t iterStride = 1)
 {
     sc.stri         = c->dShadeTris;
     sc.sobolBytes   = c->dSobolBytes;
@@ -756,7 +788,9 @@ static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& 
     }
     f.w       = c->w;
     f.h       = c->h;
-    f.npix    = c->npix;
+    f.npix    = c->npix * nsub;
+    f.npixImg = c->npix;
+    f.iterStride = iterStride;
     f.accum   = c->accum;
     f.rayO    = p.rayO;
     f.rayD    = p.rayD;
@@ -812,29 +846,31 @@ static int render_ao(prt_context* c)
 
 // One pass of pathRT.rgen (one aaRay of one vkCmdTraceRaysNV(W,H,1)): a fixed launch sequence on the pipe's
 // stream, then k_resolve on the main stream (iteration order). No host synchronisation.
-static int render_path_pass(prt_context* c, int pi, int aa)
+static int render_path_pass(prt_context* c, int pi, int aa, uint32_t nsub = 1, uint32_t iterStride = 1)
 {
-    Pipe& p = c->pipes[pi];
-    if(!p.allocated)
+    Pipe&        p    = c->pipes[pi];
+    const size_t npass = (size_t)c->npix * nsub;  // "pixels" of this pass: nsub iterations side by side
+    const int    B     = c->ubo.numIndirectBounces;
+    if(!p.allocated || p.cap < npass || p.contribCap < (uint32_t)B + 1u)
     {
-        const hipError_t e = pipe_alloc(p, c->npix);
+        if(p.allocated) HIPCHK(c, sync_all(c));
+        const bool grow = p.cap < npass;
+        hipError_t e    = pipe_alloc(p, npass);
         if(e != hipSuccess) return fail(c, PRT_E_HIP, "pipe allocation failed: %s", hipGetErrorString(e));
-    }
-    const int B = c->ubo.numIndirectBounces;
-    if(p.contribCap < (uint32_t)B + 1u)
-    {
-        HIPCHK(c, sync_all(c));
-        dfree(p.contrib);
-        p.contribCap = 0;
-        HIPCHK(c, dalloc(p.contrib, (size_t)(B + 1) * c->npix));
-        p.contribCap = (uint32_t)B + 1u;
+        if(grow || p.contribCap < (uint32_t)B + 1u)
+        {
+            dfree(p.contrib);
+            p.contribCap = 0;
+            HIPCHK(c, dalloc(p.contrib, (size_t)(B + 1) * p.cap));
+            p.contribCap = (uint32_t)B + 1u;
+        }
     }
     hipStream_t st = p.stream;
     SceneView   sc;
     FrameView   f;
-    make_views(c, p, sc, f);
+    make_views(c, p, sc, f, nsub, iterStride);
     if(p.busy) HIPCHK(c, hipStreamWaitEvent(st, p.evFree, 0));  // the terms of its previous pass have been summed
-    const uint32_t gridPix   = cdiv(c->npix, 256);
+    const uint32_t gridPix   = cdiv(npass, 256);
     const uint32_t gridShade = (uint32_t)c->numCU * 8u;
     // counters: [0..31] path-queue lengths per bounce, [32..63] shadow-queue lengths,
     //           [64..127] work-fetch cursors of the extend launches, [128..191] of the shadow launches
@@ -849,12 +885,28 @@ static int render_path_pass(prt_context* c, int pi, int aa)
         const uint32_t* qIn  = b == 0 ? nullptr : p.q[b & 1];
         const uint32_t* nIn  = b == 0 ? nullptr : p.counters + b;
         uint32_t*       qOut = p.q[(b + 1) & 1];
-        launch_extend(c, st, sc, f, c->gridExtend, qIn, nIn, p.counters + 64 + b, b == 0 ? 1u : 0u);
+        // with fusion the extension rays of bounce b >= 1 were traced together with the shadow rays of bounce b-1
+        if(b == 0 || !c->fuse) launch_extend(c, st, sc, f, c->gridExtend, qIn, nIn, p.counters + 64 + b, b == 0 ? 1u : 0u);
         {
             ProfScope ps(c, PRT_K_SHADE, st);
             hipLaunchKernelGGL(k_shade, dim3(gridShade), dim3(256), 0, st, sc, f, c->ubo, fl, (uint32_t)b, qIn, nIn,
                                qOut, p.counters + b + 1, p.qShadow, p.counters + 32 + b);
         }
+        if(c->fuse && b < B)
+        {
+            ProfScope ps(c, PRT_K_SHADOW_EXTEND, st);
+            if(c->profLevel >= 2)
+                hipLaunchKernelGGL(k_shadow_extend<true>, dim3(c->gridFused), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+                                   (const uint32_t*)p.qShadow, (const uint32_t*)(p.counters + 32 + b),
+                                   p.counters + 128 + b, (uint32_t)b, (const uint32_t*)qOut,
+                                   (const uint32_t*)(p.counters + b + 1), p.counters + 64 + b + 1, trace_tune());
+            else
+                hipLaunchKernelGGL(k_shadow_extend<false>, dim3(c->gridFused), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+                                   (const uint32_t*)p.qShadow, (const uint32_t*)(p.counters + 32 + b),
+                                   p.counters + 128 + b, (uint32_t)b, (const uint32_t*)qOut,
+                                   (const uint32_t*)(p.counters + b + 1), p.counters + 64 + b + 1, trace_tune());
+        }
+        else
         {
             ProfScope ps(c, PRT_K_SHADOW, st);
             if(c->profLevel >= 2)
@@ -872,12 +924,13 @@ static int render_path_pass(prt_context* c, int pi, int aa)
     HIPCHK(c, hipStreamWaitEvent(c->stream, p.evDone, 0));
     {
         ProfScope ps(c, PRT_K_RESOLVE, c->stream);
-        hipLaunchKernelGGL(k_resolve, dim3(gridPix), dim3(256), 0, c->stream, c->accum, (const float4*)p.contrib,
-                           (const uint8_t*)p.nvert, c->npix);
+        hipLaunchKernelGGL(k_resolve, dim3(cdiv(c->npix, 256)), dim3(256), 0, c->stream, c->accum,
+                           (const float4*)p.contrib, (const uint8_t*)p.nvert, c->npix, nsub);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(p.evFree, c->stream));
     p.busy      = true;
+    p.lastSub   = nsub;
     c->lastPipe = pi;
     if(c->pending.size() > 8192) prof_collect(c);
     return PRT_OK;
@@ -921,7 +974,32 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
 {
     if(!c) return PRT_E_INVALID;
     if(stride == 0) return fail(c, PRT_E_INVALID, "prt_render: stride 0");
-    for(uint32_t k = 0; k < n; ++k)
+    // Several iterations per pass: a launch over B*W*H "pixels" has the same fixed tail as one over W*H, so small
+    // frames batch consecutive iterations (pixel k of the pass = image pixel k % (W*H) of iteration
+    // first + (k / (W*H)) * stride); k_resolve adds them in iteration order, so the image is bit-identical.
+    const bool batchable = mode == PRT_MODE_PATH && c->batch > 1 && c->nPipes > 1 && c->ubo.numAArays == 1 &&
+                           !(c->flags & PRT_FLAG_LITERAL) && c->haveAccel && !c->accelStale;
+    uint32_t k = 0;
+    if(batchable)
+    {
+        HIPCHK(c, hipSetDevice(c->device));
+        if(mode != c->lastMode)
+        {
+            HIPCHK(c, sync_all(c));
+            c->lastMode = mode;
+        }
+        while(n - k >= 2)
+        {
+            const uint32_t nsub = n - k < c->batch ? n - k : c->batch;
+            c->ubo.iteration    = first + k * stride;
+            const int rc        = render_path_pass(c, c->nextPipe, 0, nsub, stride);
+            if(rc) return rc;
+            c->nextPipe = (c->nextPipe + 1) % c->nPipes;
+            c->iterations += nsub;
+            k += nsub;
+        }
+    }
+    for(; k < n; ++k)
     {
         c->ubo.iteration = first + k * stride;
         const int rc     = prt_render_iteration(c, mode);
@@ -929,6 +1007,15 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
     }
     return PRT_OK;
 }
+
+int prt_set_iteration_batch(prt_context* c, int n)
+{
+    if(!c) return PRT_E_INVALID;
+    if(n < 1 || n > 64) return fail(c, PRT_E_LIMIT, "prt_set_iteration_batch: %d outside [1,64]", n);
+    c->batch = (uint32_t)n;
+    return PRT_OK;
+}
+int prt_get_iteration_batch(const prt_context* c) { return c ? (int)c->batch : PRT_E_INVALID; }
 
 int prt_get_pipeline_depth(const prt_context* c) { return c ? c->nPipes : PRT_E_INVALID; }
 
@@ -1015,7 +1102,8 @@ int prt_read_hit_ids(prt_context* c, uint32_t* out)
     if(!c || !out) return PRT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, sync_all(c));
-    HIPCHK(c, hipMemcpy(out, c->pipes[c->lastPipe].hitIds, (size_t)c->npix * 4, hipMemcpyDeviceToHost));
+    const Pipe& lp = c->pipes[c->lastPipe];  // the last iteration of the pipe's last pass
+    HIPCHK(c, hipMemcpy(out, lp.hitIds + (size_t)(lp.lastSub - 1) * c->npix, (size_t)c->npix * 4, hipMemcpyDeviceToHost));
     return PRT_OK;
 }
 

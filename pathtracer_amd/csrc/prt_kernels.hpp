@@ -45,7 +45,10 @@ struct SceneView
 
 struct FrameView
 {
-    uint32_t  w, h, npix;
+    uint32_t  w, h;
+    uint32_t  npix;        // pixels of this pass: npixImg times the number of iterations batched into it; "pixel" k
+                           // of the pass is image pixel k % npixImg of iteration ubo.iteration + (k / npixImg) * iterStride
+    uint32_t  npixImg, iterStride;
     float4*   accum;
     float4*   rayO;   // Ro.xyz, tmin
     float4*   rayD;   // Rd.xyz, tmax
@@ -174,10 +177,11 @@ __global__ void __launch_bounds__(256) k_generate(SceneView sc, FrameView f, con
         f.rayD[px] = make_float4(0.0f, 0.0f, 1.0f, -1.0f);  // empty interval: traces as a miss
         return;
     }
-    const uint32_t x = px % f.w, y = px / f.w;
-    const uint32_t s0 = scramble_value(sc.scrTable, f.npix, sc.seed, px, 0);
-    const uint32_t s1 = scramble_value(sc.scrTable, f.npix, sc.seed, px, 1);
-    const uint32_t sobolIndex = s0 / 2u + ubo->iteration + aa;
+    const uint32_t sub = px / f.npixImg, ip = px - sub * f.npixImg;  // iteration of the batch, image pixel
+    const uint32_t x = ip % f.w, y = ip / f.w;
+    const uint32_t s0 = scramble_value(sc.scrTable, f.npixImg, sc.seed, ip, 0);
+    const uint32_t s1 = scramble_value(sc.scrTable, f.npixImg, sc.seed, ip, 1);
+    const uint32_t sobolIndex = s0 / 2u + (ubo->iteration + sub * f.iterStride) + aa;
     f2 off;
     off.x = sobol1D(sc.sobol, sobolIndex, 2u, s0);
     off.y = sobol1D(sc.sobol, sobolIndex, 3u, s1);
@@ -350,7 +354,8 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                 if(bounce == 0 && !isDead)
                 {
                     // primary miss — pathRT.rgen:693-697
-                    const uint32_t x = px % f.w, y = px / f.w;
+                    const uint32_t ip = px % f.npixImg;
+                    const uint32_t x = ip % f.w, y = ip / f.w;
                     const float    u = ((float)x + 0.5f) / (float)f.w, v = ((float)y + 0.5f) / (float)f.h;
                     // literal: the miss colour replaces E; default: it is one more term of the sum
                     f.contrib[px] = make_float4(u, v, 0.4f, 1.0f);
@@ -369,11 +374,12 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
 
                 // sobolIndex = layer0 / 2 + iteration, +1 per finished aaRay (:627-631, :970); the aaRay
                 // ordinal travels in bits 8..15 of `flags`.
-                const uint32_t s0   = scramble_value(sc.scrTable, f.npix, sc.seed, px, 0);
-                const uint32_t sidx = s0 / 2u + ubo->iteration + ((flags >> 8) & 0xffu);
+                const uint32_t sub  = px / f.npixImg, ip = px - sub * f.npixImg;  // iteration of the batch, image pixel
+                const uint32_t s0   = scramble_value(sc.scrTable, f.npixImg, sc.seed, ip, 0);
+                const uint32_t sidx = s0 / 2u + (ubo->iteration + sub * f.iterStride) + ((flags >> 8) & 0xffu);
                 const uint32_t layer = 1u + bounce;  // scrambleArray[scrambleArrayLayer++], :664,:703
-                const uint32_t scr0  = scramble_value(sc.scrTable, f.npix, sc.seed, px, 2u * layer);
-                const uint32_t scr1  = scramble_value(sc.scrTable, f.npix, sc.seed, px, 2u * layer + 1u);
+                const uint32_t scr0  = scramble_value(sc.scrTable, f.npixImg, sc.seed, ip, 2u * layer);
+                const uint32_t scr1  = scramble_value(sc.scrTable, f.npixImg, sc.seed, ip, 2u * layer + 1u);
                 // sobolDim after the pixel offset is 4 + 4*bounce, 4 per vertex: tables 0..3 of sobT
 
                 const TriU     tri = load_tri(sc.stri, primitiveID);
@@ -546,7 +552,7 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                 {
                     // Russian roulette (extension, off by default)
                     const uint32_t b1  = bounce + 1u;
-                    const uint32_t rs  = scramble_value(sc.scrTable, f.npix, sc.seed, px, 30u + (b1 & 1u));
+                    const uint32_t rs  = scramble_value(sc.scrTable, f.npixImg, sc.seed, ip, 30u + (b1 & 1u));
                     const float    q   = gclamp(maxcoord(throughput), 0.05f, 1.0f);
                     const float    xi  = sobol1D_bytes(sobT + 4096, sidx, rs);
                     if(xi >= q)
@@ -610,29 +616,66 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_shadow(Sce
     flush_counts<INSTR>(f, count, nskip, tc, 1);
 }
 
+// The shadow rays of bounce b and the extension rays of bounce b+1 both come out of k_shade(b) and do not depend on
+// each other: one launch traces both. A wave first drains the extension queue (the next k_shade waits for it), then
+// the shadow queue, so the few long rays at the end of the first stream run beside the second stream instead of on
+// an empty GPU — one launch tail per bounce instead of two.
+template <bool INSTR>
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_shadow_extend(
+    SceneView sc, FrameView f, const uint32_t* __restrict__ shQueue, const uint32_t* __restrict__ shCountPtr,
+    uint32_t* shWork, uint32_t bounce, const uint32_t* __restrict__ exQueue, const uint32_t* __restrict__ exCountPtr,
+    uint32_t* exWork, TraceTune tune)
+{
+    __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
+    {
+        const uint32_t count = *exCountPtr;
+        uint32_t       nskip = 0;
+        TraceCount     tc    = {};
+        ExtendIO       io{f, exQueue, 0u};
+        trace_stream<false, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, exWork, tune, io, nskip, tc);
+        flush_counts<INSTR>(f, count, nskip, tc, 0);
+    }
+    {
+        const uint32_t count = *shCountPtr;
+        uint32_t       nskip = 0;
+        TraceCount     tc    = {};
+        ShadowIO       io{f, shQueue, f.contrib + (size_t)bounce * f.npix};
+        trace_stream<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, shWork, tune, io, nskip, tc);
+        flush_counts<INSTR>(f, count, nskip, tc, 1);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // resolve — E += Ei of every path vertex, in path order (pathRT.rgen:939-942, :649-654, :693-697, :973)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_resolve(float4* __restrict__ accum, const float4* __restrict__ contrib,
-                                                 const uint8_t* __restrict__ nvert, uint32_t npix)
+                                                 const uint8_t* __restrict__ nvert, uint32_t npixImg, uint32_t nsub)
 {
     const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x;
-    if(px >= npix) return;
-    const uint32_t n = nvert[px];
-    if(n == 0) return;
-    float4 E = (n & 0x80u) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : accum[px];
-    if(n & 0x40u)
-        E = ld_nt(contrib + px);
-    else
+    if(px >= npixImg) return;
+    const size_t npix = (size_t)npixImg * nsub;  // pixels of the pass = row length of contrib
+    float4       E    = accum[px];
+    bool         any  = false;
+    for(uint32_t s = 0; s < nsub; ++s)  // the iterations of the batch, in iteration order
     {
-        const uint32_t cnt = n & 0x3fu;
-        for(uint32_t b = 0; b < cnt; ++b)
+        const size_t   vp = (size_t)s * npixImg + px;
+        const uint32_t n  = nvert[vp];
+        if(n == 0) continue;
+        any = true;
+        if(n & 0x80u) E = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if(n & 0x40u)
+            E = ld_nt(contrib + vp);
+        else
         {
-            const float4 t = ld_nt(contrib + (size_t)b * npix + px);
-            E              = make_float4(E.x + t.x, E.y + t.y, E.z + t.z, E.w + t.w);
+            const uint32_t cnt = n & 0x3fu;
+            for(uint32_t b = 0; b < cnt; ++b)
+            {
+                const float4 t = ld_nt(contrib + (size_t)b * npix + vp);
+                E              = make_float4(E.x + t.x, E.y + t.y, E.z + t.z, E.w + t.w);
+            }
         }
     }
-    accum[px] = E;
+    if(any) accum[px] = E;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -168,6 +168,53 @@ def test_pipelined_iterations_equal_sequential():
         capi.Context(8, 8).set_pipeline_depth(99)
 
 
+def test_batched_iterations_equal_one_by_one(po):
+    """prt_render puts several iterations into one pass over n*W*H pixels (prt_set_iteration_batch): the image,
+    the ray count and the hit ids of the last iteration equal those of one iteration per pass — also with a stride
+    (multi-GPU share), Russian roulette, an uploaded scramble table, and a batch that does not divide the count."""
+    sc = scenes.conference_room(detail=0.4)
+    W, H = 200, 120
+    table = np.random.default_rng(3).integers(0, 2**32, (32, H, W), dtype=np.uint64).astype(np.uint32)
+    out = []
+    for batch, depth in ((1, 1), (1, 3), (2, 2), (5, 3), (8, 2)):
+        ctx = capi.Context(W, H)
+        ctx.set_scene(sc)
+        ctx.set_seed(9)
+        ctx.build_accel()
+        ctx.set_pipeline_depth(depth)
+        ctx.set_iteration_batch(batch)
+        assert ctx.iteration_batch() == batch
+        ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=4))
+        ctx.render(capi.MODE_PATH, 2, 13, 3)  # iterations 2, 5, ..., 38
+        ids = ctx.read_hit_ids().tobytes()
+        ctx.set_flags(capi.FLAG_RUSSIAN_ROULETTE)
+        ctx.upload_scrambles(table)
+        ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=6))  # more terms per pass than before
+        ctx.render(capi.MODE_PATH, 40, 7, 1)
+        out.append((ctx.read_accum().tobytes(), ctx.stats().rays, ctx.stats().iterations, ids, ctx.read_hit_ids().tobytes()))
+        ctx.close()
+    assert all(o == out[0] for o in out[1:])
+    assert out[0][2] == 20
+    # and against the oracle for the first part
+    o = po.Oracle(sc, seed=9)
+    o.build_bvh()
+    acc, last = np.zeros((H, W, 4), np.float32), None
+    ctx = capi.Context(W, H)
+    ctx.set_scene(sc)
+    ctx.set_seed(9)
+    ctx.build_accel()
+    ctx.set_iteration_batch(4)
+    ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=2))
+    ctx.render(capi.MODE_PATH, 1, 6, 1)
+    for it in range(1, 7):
+        acc, last, _ = o.render(uniforms.make_uniforms(sc, W, H, bounces=2, iteration=it), W, H, capi.MODE_PATH, accum=acc,
+                                want_ids=True)
+    assert ctx.read_accum().tobytes() == acc.tobytes() and (ctx.read_hit_ids() == last).all()
+    with pytest.raises(capi.PrtError):
+        ctx.set_iteration_batch(0)
+    ctx.close()
+
+
 def test_uploaded_scramble_table(po):
     """The reference's explicit 32-layer scramble image (vkRTX_setup.cpp:808-911) instead of the hash."""
     sc = scenes.cornell_box()
