@@ -121,6 +121,8 @@ def main():
     # warmup
     ctx.render(capi.MODE_PATH, 1 + rank, WU, n_gpus)
     ctx.sync()
+    if dist:
+        dist.all_reduce(accum, op=dist.ReduceOp.SUM)  # warm-up of the collective at its real size (untimed)
     accum.zero_()
     torch.cuda.synchronize()
     ctx.reset_stats()
@@ -165,12 +167,28 @@ def main():
         # S_node = 64 (BVH4 node with 16-bit boxes, four 16-byte loads)
         b_closest = 96.0 + cn * 64.0 + ct * 48.0
         b_any = 96.0 + an * 64.0 + at * 48.0
-        if p.ms[capi.K_EXTEND] >= p.ms[capi.K_SHADOW]:
-            kind, kname, b_ray, nrays = capi.K_EXTEND, "k_extend (closest-hit traversal)", b_closest, p.closest_rays
-            nn, nt = cn, ct
+        def kind_work(pp, kd):
+            """(rays, algorithmic bytes) the launches of kernel kind `kd` processed"""
+            fc, fa = pp.fused_closest_rays, pp.fused_any_rays
+            if kd == capi.K_EXTEND:
+                return pp.closest_rays - fc, (pp.closest_rays - fc) * b_closest
+            if kd == capi.K_SHADOW:
+                return pp.any_rays - fa, (pp.any_rays - fa) * b_any
+            return fc + fa, fc * b_closest + fa * b_any
+
+        names = {capi.K_EXTEND: "k_extend (closest-hit traversal)",
+                 capi.K_SHADOW: "k_shadow (any-hit traversal + accumulate)",
+                 capi.K_SHADOW_EXTEND: "k_shadow_extend (closest-hit traversal of bounce b+1 and any-hit traversal "
+                                       "of bounce b in one launch)"}
+        kind = max(names, key=lambda kd: p.ms[kd])
+        kname = names[kind]
+        nrays, nbytes = kind_work(p, kind)
+        b_ray = nbytes / max(1, nrays)
+        if kind == capi.K_SHADOW_EXTEND:
+            fr = p.fused_closest_rays / max(1, nrays)
+            nn, nt = fr * cn + (1 - fr) * an, fr * ct + (1 - fr) * at
         else:
-            kind, kname, b_ray, nrays = capi.K_SHADOW, "k_shadow (any-hit traversal + accumulate)", b_any, p.any_rays
-            nn, nt = an, at
+            nn, nt = (cn, ct) if kind == capi.K_EXTEND else (an, at)
         launches = max(1, int(p.launches[kind]))
         ms_launch = p.ms[kind] / launches
         bytes_launch = b_ray * nrays / launches
@@ -201,8 +219,9 @@ def main():
         p1 = ctx.profile()
         l1 = max(1, int(p1.launches[kind]))
         ms1 = p1.ms[kind] / l1
-        n1 = (p1.closest_rays if kind == capi.K_EXTEND else p1.any_rays) / l1
-        a1 = b_ray * n1 / (ms1 * 1e-3) / 1e9 if ms1 > 0 else 0.0
+        r1, by1 = kind_work(p1, kind)
+        n1 = r1 / l1
+        a1 = by1 / l1 / (ms1 * 1e-3) / 1e9 if ms1 > 0 else 0.0
         roofline["standalone"] = {"ms_per_launch": round(ms1, 4), "achieved": round(a1, 2),
                                   "frac": round(a1 / HBM_PEAK_GBS, 5), "rays_per_launch": round(n1, 1),
                                   "what": "same kernel with pipeline depth 1 (no other kernel sharing the GPU)"}
@@ -252,7 +271,7 @@ def main():
                        "iterations_per_gpu": K, "parallelism": f"spp-sharded x{n_gpus}" if n_gpus > 1 else "single GPU",
                        "rays_total": int(total_rays), "rays_per_sample": round(total_rays / (K * n_gpus * W * H), 3),
                        "bvh_build_ms": round(st.bvh_build_ms, 2), "image_finite": finite,
-                       "iterations_in_flight": in_flight, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
+                       "iterations_in_flight": in_flight, "iterations_per_pass": ctx.iteration_batch(), "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "kernels": kernels,

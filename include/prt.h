@@ -101,6 +101,7 @@ typedef struct prt_profile
     uint64_t closest_nodes, closest_tris; /* 64-byte nodes fetched / triangles tested by closest-hit rays */
     uint64_t any_nodes, any_tris;         /* ... by any-hit rays (both only at profiling level 2) */
     prt_wave_steps closest_steps, any_steps;
+    uint64_t fused_closest_rays, fused_any_rays; /* the part of closest_rays / any_rays traced by PRT_K_SHADOW_EXTEND launches */
 } prt_profile;
 
 /* VkRTX::VkRTX(ctx, extent) — vkRTX_setup.h:20-24. Binds to HIP device `device_ordinal`. */

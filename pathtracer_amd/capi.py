@@ -50,7 +50,7 @@ class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8), ("closest_rays", C.c_uint64),
                 ("any_rays", C.c_uint64), ("closest_nodes", C.c_uint64), ("closest_tris", C.c_uint64),
                 ("any_nodes", C.c_uint64), ("any_tris", C.c_uint64), ("closest_steps", WaveSteps),
-                ("any_steps", WaveSteps)]
+                ("any_steps", WaveSteps), ("fused_closest_rays", C.c_uint64), ("fused_any_rays", C.c_uint64)]
 
 
 class _Tex(C.Structure):

@@ -977,7 +977,7 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
     // Several iterations per pass: a launch over B*W*H "pixels" has the same fixed tail as one over W*H, so small
     // frames batch consecutive iterations (pixel k of the pass = image pixel k % (W*H) of iteration
     // first + (k / (W*H)) * stride); k_resolve adds them in iteration order, so the image is bit-identical.
-    const bool batchable = mode == PRT_MODE_PATH && c->batch > 1 && c->nPipes > 1 && c->ubo.numAArays == 1 &&
+    const bool batchable = mode == PRT_MODE_PATH && c->batch > 1 && c->ubo.numAArays == 1 &&
                            !(c->flags & PRT_FLAG_LITERAL) && c->haveAccel && !c->accelStale;
     uint32_t k = 0;
     if(batchable)
@@ -1170,6 +1170,8 @@ int prt_get_profile(prt_context* c, prt_profile* out)
     out->closest_tris  = st[3];
     out->any_nodes     = st[4];
     out->any_tris      = st[5];
+    out->fused_closest_rays = st[6];
+    out->fused_any_rays     = st[7];
     for(int k = 0; k < 2; ++k)
     {
         prt_wave_steps& w = k == 0 ? out->closest_steps : out->any_steps;

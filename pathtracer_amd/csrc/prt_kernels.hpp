@@ -634,6 +634,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_shadow_ext
         ExtendIO       io{f, exQueue, 0u};
         trace_stream<false, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, exWork, tune, io, nskip, tc);
         flush_counts<INSTR>(f, count, nskip, tc, 0);
+        if(blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(f.stats + 6, (unsigned long long)count);
     }
     {
         const uint32_t count = *shCountPtr;
@@ -642,6 +643,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_shadow_ext
         ShadowIO       io{f, shQueue, f.contrib + (size_t)bounce * f.npix};
         trace_stream<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, shWork, tune, io, nskip, tc);
         flush_counts<INSTR>(f, count, nskip, tc, 1);
+        if(blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(f.stats + 7, (unsigned long long)count);
     }
 }
 

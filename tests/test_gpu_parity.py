@@ -176,7 +176,7 @@ def test_batched_iterations_equal_one_by_one(po):
     W, H = 200, 120
     table = np.random.default_rng(3).integers(0, 2**32, (32, H, W), dtype=np.uint64).astype(np.uint32)
     out = []
-    for batch, depth in ((1, 1), (1, 3), (2, 2), (5, 3), (8, 2)):
+    for batch, depth in ((1, 1), (1, 3), (2, 2), (5, 3), (8, 2), (4, 1)):
         ctx = capi.Context(W, H)
         ctx.set_scene(sc)
         ctx.set_seed(9)

@@ -15,7 +15,7 @@ out = [f"# rocprofv3 summary ({tag}) — `python3 bench.py --steps 8 --warmup 2 
 db = sqlite3.connect(os.path.join(G, "prof_trace", "trace_results.db"))
 out.append("## `rocprofv3 --kernel-trace --stats` (top kernels; durations in microseconds)\n")
 out.append("| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|")
-for name, calls, tot, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 16"):
+for name, calls, tot, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 18"):
     out.append(f"| `{short(name)}` | {calls} | {tot:.1f} | {avg:.2f} | {pct:.2f} |")
 # register / LDS / scratch usage
 out.append("\n| kernel | VGPR | SGPR | LDS B | scratch B | grid | block |\n|---|---:|---:|---:|---:|---:|---:|")
@@ -42,7 +42,7 @@ out.append("FETCH_SIZE / WRITE_SIZE are reported in KiB; per MI355X_MICROARCH.md
            "requests at 64 B for 16-byte-per-lane loads on gfx950, so the `HBM read` column is FETCH_SIZE x 2. The counters sit at the L2's "
            "fabric side, so Infinity-Cache hits are included: this is traffic leaving L2, an upper bound on HBM traffic.\n")
 out.append("| kernel | launches | FETCH_SIZE KiB/launch (raw) | read MB/launch (x2) | WRITE_SIZE KiB/launch | L2 hit rate | VALU busy (SQ_ACTIVE_INST_VALU*4/SQ_BUSY_CYCLES... see below) |\n|---|---:|---:|---:|---:|---:|---:|")
-for k in ["prt::k_extend<false>", "prt::k_shadow<false>", "prt::k_shade", "prt::k_generate", "prt::k_resolve"]:
+for k in ["prt::k_shadow_extend<false>", "prt::k_extend<false>", "prt::k_shadow<false>", "prt::k_shade", "prt::k_generate", "prt::k_resolve"]:
     if k not in fetch: continue
     f = fetch[k]["FETCH_SIZE"] / nf[k]; w = write[k]["WRITE_SIZE"] / nw[k]
     h = tcc[k].get("TCC_HIT_sum", 0.0); m = tcc[k].get("TCC_MISS_sum", 0.0)
@@ -55,7 +55,7 @@ for k in ["prt::k_extend<false>", "prt::k_shadow<false>", "prt::k_shade", "prt::
                                                        "valu_active_per_wave_cycle": round(util, 4)}
 out.append("\nLast column = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (fraction of resident-wave cycles in which the wave is issuing VALU work).\n")
 out.append("### raw SQ counters (sum over launches)\n")
-for k in ["prt::k_extend<false>", "prt::k_shadow<false>", "prt::k_shade"]:
+for k in ["prt::k_shadow_extend<false>", "prt::k_extend<false>", "prt::k_shadow<false>", "prt::k_shade"]:
     if k in sq: out.append(f"* `{k}`: " + ", ".join(f"{c}={v:.4g}" for c, v in sorted(sq[k].items())))
 open(os.path.join(P, f"{tag}_rocprof_summary.md"), "w").write("\n".join(out) + "\n")
 json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
