@@ -180,6 +180,9 @@ int prt_reset_stats(prt_context* ctx);
  * events on the context's stream; 2: additionally run the traversal kernels in their instrumented form that
  * counts node fetches and triangle tests. prt_get_profile is synchronous; totals since prt_reset_stats. */
 int prt_set_profiling(prt_context* ctx, int level);
+/* Restrict the event brackets to the kernel kinds in `kinds` (bit PRT_K_*; default: all). Two events per launch on
+ * every kernel cost the pipelined render about a tenth of its rate; bracketing only the kernel under study does not. */
+int prt_set_profiling_mask(prt_context* ctx, uint32_t kinds);
 int prt_get_profile(prt_context* ctx, prt_profile* out);
 
 /* traceNV for a batch of host rays (closest hit, or any_hit != 0 for the terminate-on-first-hit

@@ -22,7 +22,7 @@ EXPORTS = [
     "prt_upload_scrambles", "prt_set_uniforms", "prt_set_flags", "prt_render_iteration", "prt_render", "prt_sync",
     "prt_clear_accum", "prt_read_accum", "prt_device_accum_ptr", "prt_bind_accum", "prt_postprocess",
     "prt_read_hit_ids", "prt_get_stats", "prt_reset_stats", "prt_trace", "prt_trace_device", "prt_read_bvh",
-    "prt_read_sobol", "prt_set_profiling", "prt_get_profile", "prt_set_pipeline_depth", "prt_get_pipeline_depth",
+    "prt_read_sobol", "prt_set_profiling", "prt_set_profiling_mask", "prt_get_profile", "prt_set_pipeline_depth", "prt_get_pipeline_depth",
     "prt_update_vertices", "prt_refit_accel", "prt_write_accum", "prt_set_iteration_batch", "prt_get_iteration_batch",
     "prt_group_create", "prt_group_destroy", "prt_group_last_error", "prt_group_size", "prt_group_uses_rccl",
     "prt_group_context", "prt_group_set_scene", "prt_group_set_scramble_seed", "prt_group_set_uniforms",
@@ -99,6 +99,7 @@ def lib():
         L.prt_read_sobol.argtypes = [vp, vp]
         L.prt_set_profiling.argtypes = [vp, i32]
         L.prt_get_profile.argtypes = [vp, C.POINTER(Profile)]
+        L.prt_set_profiling_mask.argtypes = [vp, C.c_uint32]
         L.prt_set_pipeline_depth.argtypes = [vp, i32]
         L.prt_get_pipeline_depth.argtypes = [vp]
         L.prt_set_iteration_batch.argtypes = [vp, i32]
@@ -271,6 +272,9 @@ class Context:
 
     def set_profiling(self, level):
         self._chk(self.L.prt_set_profiling(self.h_, level))
+
+    def set_profiling_mask(self, kinds):
+        self._chk(self.L.prt_set_profiling_mask(self.h_, kinds))
 
     def profile(self):
         p = Profile()

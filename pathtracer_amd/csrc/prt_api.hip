@@ -50,7 +50,7 @@ struct prt_context
     uint32_t    w = 0, h = 0, npix = 0;
     uint32_t    flags = 0, seed = 1;
     int         numCU = 256;
-    uint32_t    gridExtend = 0, gridShadow = 0, gridBatch = 0, gridAo = 0, gridFused = 0;
+    uint32_t    gridExtend = 0, gridShadow = 0, gridBatch = 0, gridAo = 0, gridFused = 0, gridShade = 0;
     bool        fuse = true;  // shadow(b) + extend(b+1) in one launch (PRT_FUSE=0 turns it off)
     uint32_t    batch = 1;    // iterations per pass in prt_render (see there)  // resident blocks of the persistent kernels
     std::string err;
@@ -96,6 +96,7 @@ struct prt_context
 
     // profiling
     int profLevel = 0;
+    uint32_t    profMask = 0xffffffffu;  // kernel kinds that get events (prt_set_profiling_mask)
     struct Pending
     {
         int        kind;
@@ -290,10 +291,18 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
         c->gridBatch  = resident((const void*)k_trace_batch<false>);
         c->gridAo     = resident((const void*)k_ao_shade);
         c->gridFused  = resident((const void*)k_shadow_extend<false>);
-        if(const char* fe = getenv("PRT_FUSE")) c->fuse = atoi(fe) != 0;
-        // default batch: enough iterations to put ~8 M pixels into a pass (a 4K frame's worth), at most 8
+        // k_shade strides over its queue with a fixed stride: every block must be resident from the start, or the
+        // late blocks do their whole share on a nearly empty GPU
+        c->gridShade  = resident((const void*)k_shade);
+        if(const char* g = getenv("PRT_SHADE_BLOCKS_PER_CU"))
         {
-            const uint64_t target = 8ull << 20;
+            const int nb = atoi(g);
+            if(nb >= 1 && nb <= 16) c->gridShade = (uint32_t)nb * (uint32_t)c->numCU;
+        }
+        if(const char* fe = getenv("PRT_FUSE")) c->fuse = atoi(fe) != 0;
+        // default batch: enough iterations to put ~16 M pixels into a pass (8 at 1080p, 2 at 4K), at most 8
+        {
+            const uint64_t target = 16ull << 20;
             uint64_t       b      = (target + c->npix / 2) / c->npix;
             c->batch              = (uint32_t)(b < 1 ? 1 : (b > 8 ? 8 : b));
             if(const char* be = getenv("PRT_BATCH"))
@@ -746,7 +755,7 @@ struct ProfScope
     hipEvent_t   e0 = nullptr;
     ProfScope(prt_context* c_, int k, hipStream_t s_) : c(c_), kind(k), st(s_)
     {
-        if(c->profLevel > 0)
+        if(c->profLevel > 0 && ((c->profMask >> k) & 1u))
         {
             e0 = prof_event(c);
             (void)hipEventRecord(e0, st);
@@ -846,24 +855,40 @@ static int render_ao(prt_context* c)
 
 // One pass of pathRT.rgen (one aaRay of one vkCmdTraceRaysNV(W,H,1)): a fixed launch sequence on the pipe's
 // stream, then k_resolve on the main stream (iteration order). No host synchronisation.
+// buffers of one pipe for a pass over npass pixels with B bounces
+static int pipe_ensure(prt_context* c, Pipe& p, size_t npass, int B)
+{
+    if(p.allocated && p.cap >= npass && p.contribCap >= (uint32_t)B + 1u) return PRT_OK;
+    if(p.allocated) HIPCHK(c, sync_all(c));
+    const bool grow = p.cap < npass;
+    hipError_t e    = pipe_alloc(p, npass);
+    if(e != hipSuccess) return fail(c, PRT_E_HIP, "pipe allocation failed: %s", hipGetErrorString(e));
+    if(grow || p.contribCap < (uint32_t)B + 1u)
+    {
+        dfree(p.contrib);
+        p.contribCap = 0;
+        HIPCHK(c, dalloc(p.contrib, (size_t)(B + 1) * p.cap));
+        p.contribCap = (uint32_t)B + 1u;
+    }
+    return PRT_OK;
+}
+
 static int render_path_pass(prt_context* c, int pi, int aa, uint32_t nsub = 1, uint32_t iterStride = 1)
 {
-    Pipe&        p    = c->pipes[pi];
+    Pipe&        p     = c->pipes[pi];
     const size_t npass = (size_t)c->npix * nsub;  // "pixels" of this pass: nsub iterations side by side
     const int    B     = c->ubo.numIndirectBounces;
-    if(!p.allocated || p.cap < npass || p.contribCap < (uint32_t)B + 1u)
+    // all pipes of the rotation at once: an allocation synchronises the device, so it must not happen in the middle
+    // of a render (the first pass on pipe 0 would otherwise run alone, then wait for pipe 1's buffers, ...)
+    for(int q = 0; q < c->nPipes; ++q)
     {
-        if(p.allocated) HIPCHK(c, sync_all(c));
-        const bool grow = p.cap < npass;
-        hipError_t e    = pipe_alloc(p, npass);
-        if(e != hipSuccess) return fail(c, PRT_E_HIP, "pipe allocation failed: %s", hipGetErrorString(e));
-        if(grow || p.contribCap < (uint32_t)B + 1u)
-        {
-            dfree(p.contrib);
-            p.contribCap = 0;
-            HIPCHK(c, dalloc(p.contrib, (size_t)(B + 1) * p.cap));
-            p.contribCap = (uint32_t)B + 1u;
-        }
+        const int rc = pipe_ensure(c, c->pipes[q], npass, B);
+        if(rc) return rc;
+    }
+    if(pi >= c->nPipes)
+    {
+        const int rc = pipe_ensure(c, p, npass, B);
+        if(rc) return rc;
     }
     hipStream_t st = p.stream;
     SceneView   sc;
@@ -871,7 +896,7 @@ static int render_path_pass(prt_context* c, int pi, int aa, uint32_t nsub = 1, u
     make_views(c, p, sc, f, nsub, iterStride);
     if(p.busy) HIPCHK(c, hipStreamWaitEvent(st, p.evFree, 0));  // the terms of its previous pass have been summed
     const uint32_t gridPix   = cdiv(npass, 256);
-    const uint32_t gridShade = (uint32_t)c->numCU * 8u;
+    const uint32_t gridShade = c->gridShade;
     // counters: [0..31] path-queue lengths per bounce, [32..63] shadow-queue lengths,
     //           [64..127] work-fetch cursors of the extend launches, [128..191] of the shadow launches
     HIPCHK(c, hipMemsetAsync(p.counters, 0, kCounterWords * 4, st));
@@ -992,9 +1017,12 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
         {
             const uint32_t nsub = n - k < c->batch ? n - k : c->batch;
             c->ubo.iteration    = first + k * stride;
-            const int rc        = render_path_pass(c, c->nextPipe, 0, nsub, stride);
+            // big passes leave little tail to fill: two in flight are enough, a third only adds contention (measured)
+            const int rot = ((uint64_t)c->npix * nsub >= (12ull << 20) && c->nPipes > 2) ? 2 : c->nPipes;
+            if(c->nextPipe >= rot) c->nextPipe = 0;
+            const int rc = render_path_pass(c, c->nextPipe, 0, nsub, stride);
             if(rc) return rc;
-            c->nextPipe = (c->nextPipe + 1) % c->nPipes;
+            c->nextPipe = (c->nextPipe + 1) % rot;
             c->iterations += nsub;
             k += nsub;
         }
@@ -1148,6 +1176,13 @@ int prt_set_profiling(prt_context* c, int level)
     HIPCHK(c, hipSetDevice(c->device));
     prof_collect(c);
     c->profLevel = level;
+    return PRT_OK;
+}
+
+int prt_set_profiling_mask(prt_context* c, uint32_t kinds)
+{
+    if(!c) return PRT_E_INVALID;
+    c->profMask = kinds;
     return PRT_OK;
 }
 

@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) k_gather_shading(const prt_vertex* __rest
 }
 
 #ifndef PRT_SHADE_WAVES
-#define PRT_SHADE_WAVES 2
+#define PRT_SHADE_WAVES 4  // 128 VGPRs, no scratch; 5 or 6 spill and are slower, 2-3 leave the compiler 132 VGPRs = 3 waves per SIMD
 #endif
 __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,
                                                uint32_t bounce, const uint32_t* __restrict__ queueIn,

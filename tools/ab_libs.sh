@@ -4,7 +4,7 @@
 one() {
   PRT_LIB="$PWD/$1" timeout -k 10 200 python bench.py --steps 12 --warmup 2 --no-cpu-baseline "${@:3}" 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); k=d['kernels']
+d=json.loads(sys.stdin.read()); k=d['kernels_standalone']
 print('$1', '$2', 'Mrays/s', d['value'], 'ms/step', d['ms_per_step'], {n: k[n]['ms_per_launch'] for n in ('extend','shadow','shade')}, 'standalone', (d['roofline'].get('standalone') or {}).get('ms_per_launch'), flush=True)" || exit 1
 }
 for l in "$@"; do

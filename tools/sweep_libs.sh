@@ -3,6 +3,6 @@
 for l in "$@"; do
   PRT_LIB="$PWD/$l" timeout -k 10 200 python bench.py --steps 12 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); k=d['kernels']
+d=json.loads(sys.stdin.read()); k=d['kernels_standalone']
 print('$l', 'Mrays/s', d['value'], 'ms/step', d['ms_per_step'], 'extend', k['extend']['ms_per_launch'], 'shadow', k['shadow']['ms_per_launch'], 'shade', k['shade']['ms_per_launch'], flush=True)" || exit 1
 done
