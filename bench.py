@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel event timing (roofline = null)")
     ap.add_argument("--pipes", type=int, default=0, help="iterations in flight per GPU (0 = library default)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing "
+                                                       "the N > 1 code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: ranks beyond the GPU count share cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,13 +75,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    if args.share_gpu and local >= torch.cuda.device_count():
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist_
 
         dist = dist_
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from pathtracer_amd import capi, scenes, uniforms
 

@@ -11,7 +11,7 @@ def short(n):
     n = n.replace("void ", "")
     return n.split("(")[0]
 
-out = [f"# rocprofv3 summary ({tag}) — `python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline` on one MI355X\n"]
+out = [f"# rocprofv3 summary ({tag}) — `python3 bench.py --steps 16 --warmup 8 --no-cpu-baseline --pipes 1` on one MI355X (one pass in flight, so that a kernel's trace duration is its own; every path-tracing launch covers 8 iterations = 16.6 M pixels)\n"]
 db = sqlite3.connect(os.path.join(G, "prof_trace", "trace_results.db"))
 out.append("## `rocprofv3 --kernel-trace --stats` (top kernels; durations in microseconds)\n")
 out.append("| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|")
