@@ -29,7 +29,7 @@ static constexpr int      kMaxPipes     = 8;
 struct Pipe
 {
     hipStream_t stream = nullptr;
-    float4 *    rayO = nullptr, *rayD = nullptr, *hit = nullptr, *thr = nullptr, *shO = nullptr, *shD = nullptr,
+    float4 *    rayO = nullptr, *rayD = nullptr, *hit = nullptr, *thr = nullptr, *shD = nullptr,
            *eiVis = nullptr, *contrib = nullptr;
     float2*    aaOff  = nullptr;
     uint32_t*  hitIds = nullptr;
@@ -155,7 +155,7 @@ static void pipe_free(Pipe& p)
 }
 static void pipe_free_buffers(Pipe& p)
 {
-    dfree(p.rayO); dfree(p.rayD); dfree(p.hit); dfree(p.thr); dfree(p.shO); dfree(p.shD); dfree(p.eiVis);
+    dfree(p.rayO); dfree(p.rayD); dfree(p.hit); dfree(p.thr); dfree(p.shD); dfree(p.eiVis);
     dfree(p.contrib); dfree(p.aaOff); dfree(p.hitIds); dfree(p.dead); dfree(p.nvert); dfree(p.q[0]); dfree(p.q[1]);
     dfree(p.qShadow);
     p.contribCap = 0;
@@ -179,7 +179,6 @@ static hipError_t pipe_alloc(Pipe& p, size_t n)
     if(e == hipSuccess) e = dalloc(p.rayD, n);
     if(e == hipSuccess) e = dalloc(p.hit, n);
     if(e == hipSuccess) e = dalloc(p.thr, n);
-    if(e == hipSuccess) e = dalloc(p.shO, n);
     if(e == hipSuccess) e = dalloc(p.shD, n);
     if(e == hipSuccess) e = dalloc(p.eiVis, n);
     if(e == hipSuccess) e = dalloc(p.aaOff, n);
@@ -805,7 +804,6 @@ static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& 
     f.rayD    = p.rayD;
     f.hit     = p.hit;
     f.thr     = p.thr;
-    f.shO     = p.shO;
     f.shD     = p.shD;
     f.eiVis   = p.eiVis;
     f.contrib = p.contrib;
@@ -1018,7 +1016,8 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
             const uint32_t nsub = n - k < c->batch ? n - k : c->batch;
             c->ubo.iteration    = first + k * stride;
             // big passes leave little tail to fill: two in flight are enough, a third only adds contention (measured)
-            const int rot = ((uint64_t)c->npix * nsub >= (12ull << 20) && c->nPipes > 2) ? 2 : c->nPipes;
+            static const bool rotAll = getenv("PRT_ROT_ALL") != nullptr;  // measurement only
+            const int rot = ((uint64_t)c->npix * nsub >= (12ull << 20) && c->nPipes > 2 && !rotAll) ? 2 : c->nPipes;
             if(c->nextPipe >= rot) c->nextPipe = 0;
             const int rc = render_path_pass(c, c->nextPipe, 0, nsub, stride);
             if(rc) return rc;

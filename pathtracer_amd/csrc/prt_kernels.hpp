@@ -54,7 +54,7 @@ struct FrameView
     float4*   rayD;   // Rd.xyz, tmax
     float4*   hit;    // prim bits, u, v, t
     float4*   thr;    // throughput.xyz, p
-    float4*   shO;    // hitPoint.xyz, color.w
+    // hitPoint.xyz, color.w
     float4*   shD;    // vLight.xyz, -
     float4*   eiVis;  // radiance term if the light sample is visible (w = color.w)
     float4*   contrib;  // [vertex][npix]: radiance term of every path vertex of this pass (w = color.w)
@@ -346,7 +346,11 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
         if(i < count)
         {
             px                 = queueIn ? queueIn[i] : i;
+            // everything that depends on px only is requested together (one round trip, not one per use)
             const float4   hq  = f.hit[px];
+            const float4   rd4 = f.rayD[px];
+            const float4   th4 = f.thr[px];
+            const uint32_t nv0 = literal ? (uint32_t)(f.nvert[px] & 0x80) : 0u;  // set by k_generate in literal mode only
             const uint32_t primitiveID = (uint32_t)__float_as_int(hq.x);
             const bool     isDead      = (bounce == 0) && f.dead[px];
             if(primitiveID == 0xffffffffu || isDead)
@@ -359,15 +363,13 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                     const float    u = ((float)x + 0.5f) / (float)f.w, v = ((float)y + 0.5f) / (float)f.h;
                     // literal: the miss colour replaces E; default: it is one more term of the sum
                     f.contrib[px] = make_float4(u, v, 0.4f, 1.0f);
-                    f.nvert[px]   = (uint8_t)((f.nvert[px] & 0x80) | (literal ? 0x41 : 0x01));
+                    f.nvert[px]   = (uint8_t)(nv0 | (literal ? 0x41u : 0x01u));
                     f.dead[px]    = 1;
                 }
             }
             else
             {
-                const float4 rd4 = f.rayD[px];
                 const f3     Rd  = mk3(rd4.x, rd4.y, rd4.z);
-                const float4 th4 = f.thr[px];
                 f3           throughput = mk3(th4.x, th4.y, th4.z);
                 float        p          = th4.w;
                 const f3     bary       = mk3(1.0f - hq.y - hq.z, hq.y, hq.z);  // pathRT.rchit:19
@@ -532,11 +534,12 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                 EiO          = EiO * tc;
                 EiV          = EiV + em;
                 EiV          = EiV * tc;
-                f.shO[px]    = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, colorw);
+                // origin of the shadow ray and of the extension ray alike (:805, :922), tmin 1e-6 for both
+                f.rayO[px]   = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, 0.000001f);
                 f.shD[px]    = make_float4(vLight.x, vLight.y, vLight.z, 0.0f);
                 f.eiVis[px]  = make_float4(EiV.x, EiV.y, EiV.z, colorw);
                 f.contrib[(size_t)bounce * f.npix + px] = make_float4(EiO.x, EiO.y, EiO.z, colorw);
-                f.nvert[px]  = (uint8_t)((f.nvert[px] & 0x80) | (bounce + 1u));
+                f.nvert[px]  = (uint8_t)(nv0 | (bounce + 1u));
                 shadowQ      = true;
 
                 // termination — :944-961
@@ -562,7 +565,6 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                 }
                 if(alive)
                 {
-                    f.rayO[px] = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, 0.000001f);
                     f.rayD[px] = make_float4(Rn.x, Rn.y, Rn.z, 1.0f);
                     f.thr[px]  = make_float4(throughput.x, throughput.y, throughput.z, p);
                     nextQ      = true;
@@ -587,7 +589,7 @@ struct ShadowIO
     PRT_DEV bool load(uint32_t i, f3& o, float& tmin, f3& d, float& tmax, uint32_t& tag) const
     {
         const uint32_t px = ld_nt(queue + i);
-        const float4   oq = ld_nt(f.shO + px), dq = ld_nt(f.shD + px);
+        const float4   oq = ld_nt(f.rayO + px), dq = ld_nt(f.shD + px);
         o    = mk3(oq.x, oq.y, oq.z);
         tmin = 0.000001f;
         d    = mk3(dq.x, dq.y, dq.z);
