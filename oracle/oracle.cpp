@@ -198,10 +198,10 @@ inline uint32_t scrambleValue(const orc_scene& sc, uint32_t px, uint32_t py, uin
 
 // ------------------------------------------------------------------------------------------------
 // BVH: binned SAH, breadth-first, deterministic (stands in for vkCmdBuildAccelerationStructureNV,
-// vkRT_BLAS.cpp:271 — PARITY UNPINNED). 16 bins, leaves <= 4 triangles.
+// vkRT_BLAS.cpp:271 — PARITY UNPINNED). 16 bins, leaves <= 2 triangles.
 // ------------------------------------------------------------------------------------------------
 const int      NB       = 16;
-const uint32_t LEAF_MAX = 4;
+const uint32_t LEAF_MAX = 2;
 
 // total order on floats used for box min/max (distinguishes -0 < +0 like the GPU's integer atomics)
 inline uint32_t fkey(float f)

@@ -100,7 +100,7 @@ def test_config4_san_miguel_scale_10m_4k_properties():
     nodes, order = ctx.read_bvh()
     assert np.array_equal(np.sort(order), np.arange(ntri, dtype=np.uint32))  # every triangle in exactly one leaf
     leaf = nodes["count"] > 0
-    assert nodes["count"][leaf].sum() == ntri and nodes["count"].max() <= 4
+    assert nodes["count"][leaf].sum() == ntri and nodes["count"].max() <= 2
     inner = np.flatnonzero(~leaf)
     for c in (nodes["first"][inner], nodes["first"][inner] + 1):  # child boxes inside the parent box
         assert (nodes["bmin"][c] >= nodes["bmin"][inner]).all() and (nodes["bmax"][c] <= nodes["bmax"][inner]).all()
