@@ -222,7 +222,7 @@ static void prof_collect(prt_context* c);
 static TraceTune trace_tune()
 {
     static TraceTune t = [] {
-        TraceTune v{24u, 24u, 8u, 0u};
+        TraceTune v{16u, 24u, 8u, 0u};
         if(const char* e = getenv("PRT_TUNE"))
         {
             unsigned a = v.refillMin, b = v.stallMax, d = v.leafMin;

@@ -28,20 +28,25 @@
 namespace prt {
 
 #ifndef PRT_LDS_STACK
-#define PRT_LDS_STACK 24
+#define PRT_LDS_STACK 20
+#endif
+// Loading a leaf's next triangle while the current one is tested costs 14 VGPRs = the sixth wave per SIMD. With
+// leaves of <= 2 triangles the sixth wave is worth more (measured: 2.33 -> 2.30 ms); with leaves of <= 4 it was not.
+#ifndef PRT_TRI_PREFETCH
+#define PRT_TRI_PREFETCH 0
 #endif
 #define PRT_SPILL_STACK 80
 #define PRT_MAX_DEPTH 64  // depth limit of the binary build tree (=> <= 33 BVH4 levels, <= 100 stack entries)
 #define PRT_TRACE_BLOCK 256
 #ifndef PRT_TRACE_WAVES
-#define PRT_TRACE_WAVES 4  // minimum waves per SIMD the traversal kernels are compiled for
+#define PRT_TRACE_WAVES 6  // waves per SIMD the traversal kernels are compiled for (78 VGPRs; 6 x 20 KiB of LDS per CU)
 #endif
 #define PRT_NODE_BYTES 64
 #ifndef PRT_CHUNK
 #define PRT_CHUNK 128u
 #endif
 
-static_assert(1 + 3 * (PRT_MAX_DEPTH / 2 + 1) <= 24 + PRT_SPILL_STACK && PRT_LDS_STACK >= 8, "stack covers the deepest tree");
+static_assert(1 + 3 * (PRT_MAX_DEPTH / 2 + 1) <= PRT_LDS_STACK + PRT_SPILL_STACK && PRT_LDS_STACK >= 8, "stack covers the deepest tree");
 
 constexpr int32_t kSentinel  = 0x7fffffff;  // bottom-of-stack marker: the ray is finished
 constexpr int32_t kEmptyLeaf = -1;          // ~0: leaf reference with count 0
@@ -293,11 +298,13 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
     const uint32_t first = ref >> 3, count = ref & 7u;
     if(count == 0) return false;
     const float4* t = bvh.tris + (size_t)first * 3;
+#if PRT_TRI_PREFETCH
     float4        a = t[0], b = t[1], c = t[2];
+#endif
     for(uint32_t i = 0; i < count; ++i)
     {
-        // the next triangle's loads are in flight while this one is tested (dropping this saves 14 VGPRs and gives
-        // 6-7 waves per SIMD instead of 5, measured: 1-4 % slower)
+#if PRT_TRI_PREFETCH
+        // the next triangle's loads are in flight while this one is tested
         float4 na = a, nb = b, nc = c;
         if(i + 1 < count)
         {
@@ -305,6 +312,9 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
             nb = t[3 * i + 4];
             nc = t[3 * i + 5];
         }
+#else
+        const float4 a = t[3 * i], b = t[3 * i + 1], c = t[3 * i + 2];
+#endif
         float tt, uu, vv;
         if(INSTR) tc.tris++;
         if(tri_test(r, a, b, c, tt, uu, vv))
@@ -324,9 +334,11 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
                 best.prim = p;
             }
         }
+#if PRT_TRI_PREFETCH
         a = na;
         b = nb;
         c = nc;
+#endif
     }
     return false;
 }
