@@ -243,8 +243,11 @@ struct ExtendIO
     }
 };
 
+#ifndef PRT_TRACE_ATTR
+#define PRT_TRACE_ATTR
+#endif
 template <bool INSTR>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_extend(SceneView sc, FrameView f, const uint32_t* __restrict__ queue,
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) PRT_TRACE_ATTR k_extend(SceneView sc, FrameView f, const uint32_t* __restrict__ queue,
                                                             const uint32_t* __restrict__ countPtr,
                                                             uint32_t* workCtr, uint32_t primary, TraceTune tune)
 {
@@ -604,7 +607,7 @@ struct ShadowIO
 };
 
 template <bool INSTR>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_shadow(SceneView sc, FrameView f,
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow(SceneView sc, FrameView f,
                                                             const uint32_t* __restrict__ queue,
                                                             const uint32_t* __restrict__ countPtr, uint32_t* workCtr,
                                                             uint32_t bounce, TraceTune tune)
@@ -623,7 +626,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_shadow(Sce
 // the shadow queue, so the few long rays at the end of the first stream run beside the second stream instead of on
 // an empty GPU — one launch tail per bounce instead of two.
 template <bool INSTR>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_shadow_extend(
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow_extend(
     SceneView sc, FrameView f, const uint32_t* __restrict__ shQueue, const uint32_t* __restrict__ shCountPtr,
     uint32_t* shWork, uint32_t bounce, const uint32_t* __restrict__ exQueue, const uint32_t* __restrict__ exCountPtr,
     uint32_t* exWork, TraceTune tune)
@@ -816,7 +819,7 @@ struct BatchIO
     }
 };
 template <bool ANY>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) k_trace_batch(BvhView bvh, const float4* __restrict__ rays,
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) PRT_TRACE_ATTR k_trace_batch(BvhView bvh, const float4* __restrict__ rays,
                                                                  uint32_t n, float4* __restrict__ hits,
                                                                  uint32_t* workCtr, TraceTune tune)
 {

@@ -35,7 +35,7 @@ namespace prt {
 #ifndef PRT_TRI_PREFETCH
 #define PRT_TRI_PREFETCH 0
 #endif
-#define PRT_SPILL_STACK 80
+#define PRT_SPILL_STACK (100 - PRT_LDS_STACK)
 #define PRT_MAX_DEPTH 64  // depth limit of the binary build tree (=> <= 33 BVH4 levels, <= 100 stack entries)
 #define PRT_TRACE_BLOCK 256
 #ifndef PRT_TRACE_WAVES
