@@ -247,7 +247,7 @@ struct ExtendIO
 #define PRT_TRACE_ATTR
 #endif
 template <bool INSTR>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) PRT_TRACE_ATTR k_extend(SceneView sc, FrameView f, const uint32_t* __restrict__ queue,
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_extend(SceneView sc, FrameView f, const uint32_t* __restrict__ queue,
                                                             const uint32_t* __restrict__ countPtr,
                                                             uint32_t* workCtr, uint32_t primary, TraceTune tune)
 {
@@ -607,7 +607,7 @@ struct ShadowIO
 };
 
 template <bool INSTR>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow(SceneView sc, FrameView f,
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow(SceneView sc, FrameView f,
                                                             const uint32_t* __restrict__ queue,
                                                             const uint32_t* __restrict__ countPtr, uint32_t* workCtr,
                                                             uint32_t bounce, TraceTune tune)
@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) PRT_TRACE_AT
 // the shadow queue, so the few long rays at the end of the first stream run beside the second stream instead of on
 // an empty GPU — one launch tail per bounce instead of two.
 template <bool INSTR>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow_extend(
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow_extend(
     SceneView sc, FrameView f, const uint32_t* __restrict__ shQueue, const uint32_t* __restrict__ shCountPtr,
     uint32_t* shWork, uint32_t bounce, const uint32_t* __restrict__ exQueue, const uint32_t* __restrict__ exCountPtr,
     uint32_t* exWork, TraceTune tune)
