@@ -231,6 +231,63 @@ def test_uploaded_scramble_table(po):
     ctx.close()
 
 
+def test_context_lifecycle_returns_device_memory():
+    """prt_destroy gives back everything prt_create / prt_render allocated (pipes grown by batched passes included):
+    free device memory stays put over ten create-render-destroy rounds (after the runtime's own pools have formed)."""
+    import torch
+
+    sc = scenes.cornell_box()
+    W, H = 256, 192
+
+    def round_trip(k):
+        ctx = capi.Context(W, H)
+        ctx.set_scene(sc)
+        ctx.build_accel()
+        ctx.set_pipeline_depth(1 + k % 3)
+        ctx.set_iteration_batch(1 + (3 * k) % 8)
+        ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=2 + k % 3))
+        ctx.render(capi.MODE_PATH, 1, 9, 1)
+        ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, ao_rays=4))
+        ctx.render_iteration(capi.MODE_AO)
+        img = ctx.read_accum()
+        ctx.close()
+        return img
+
+    first = round_trip(0)
+    for k in range(1, 4):  # the HIP runtime keeps per-stream pools it creates in the first rounds (a few hundred MiB)
+        round_trip(k)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(4, 14):
+        round_trip(k)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (8 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB over ten contexts"
+    assert np.isfinite(first[..., 3]).all()
+
+
+def test_profiling_mask_restricts_the_brackets():
+    sc = scenes.cornell_box()
+    ctx = capi.Context(128, 96)
+    ctx.set_scene(sc)
+    ctx.build_accel()
+    ctx.set_uniforms(uniforms.make_uniforms(sc, 128, 96, bounces=2))
+    ctx.set_profiling(1)
+    ctx.set_profiling_mask(1 << capi.K_SHADE)
+    ctx.reset_stats()
+    ctx.render(capi.MODE_PATH, 1, 4, 1)
+    p = ctx.profile()
+    assert p.launches[capi.K_SHADE] > 0 and p.ms[capi.K_SHADE] > 0.0
+    assert all(p.launches[k] == 0 for k in range(capi.K_COUNT) if k != capi.K_SHADE)
+    ctx.set_profiling_mask(0xffffffff)
+    ctx.reset_stats()
+    ctx.render(capi.MODE_PATH, 5, 4, 1)
+    p = ctx.profile()
+    assert p.launches[capi.K_GENERATE] > 0 and p.launches[capi.K_RESOLVE] > 0
+    assert p.fused_closest_rays + p.fused_any_rays <= p.closest_rays + p.any_rays
+    ctx.close()
+
+
 def test_api_errors():
     ctx = capi.Context(32, 32)
     with pytest.raises(capi.PrtError):
