@@ -199,9 +199,9 @@ __global__ void __launch_bounds__(256) k_generate(SceneView sc, FrameView f, con
         primary_ray(ubo->projViewInverse, x, y, f.w, f.h, off.x, off.y, Ro, Rd);
         f.aaOff[px] = make_float2(off.x, off.y);
     }
-    f.rayO[px] = make_float4(Ro.x, Ro.y, Ro.z, 0.000001f);
-    f.rayD[px] = make_float4(Rd.x, Rd.y, Rd.z, 1.0f);
-    f.thr[px]  = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    st_nt(f.rayO + px, make_float4(Ro.x, Ro.y, Ro.z, 0.000001f));
+    st_nt(f.rayD + px, make_float4(Rd.x, Rd.y, Rd.z, 1.0f));
+    st_nt(f.thr + px, make_float4(1.0f, 1.0f, 1.0f, 1.0f));
 }
 
 // AO.rgen:185-205 — pixel-centre primary ray, tmin 1e-5
@@ -348,11 +348,11 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
         uint32_t       px      = 0;
         if(i < count)
         {
-            px                 = queueIn ? queueIn[i] : i;
+            px                 = queueIn ? ld_nt(queueIn + i) : i;
             // everything that depends on px only is requested together (one round trip, not one per use)
-            const float4   hq  = f.hit[px];
-            const float4   rd4 = f.rayD[px];
-            const float4   th4 = f.thr[px];
+            const float4   hq  = ld_nt(f.hit + px);
+            const float4   rd4 = ld_nt(f.rayD + px);
+            const float4   th4 = ld_nt(f.thr + px);
             const uint32_t nv0 = literal ? (uint32_t)(f.nvert[px] & 0x80) : 0u;  // set by k_generate in literal mode only
             const uint32_t primitiveID = (uint32_t)__float_as_int(hq.x);
             const bool     isDead      = (bounce == 0) && f.dead[px];
@@ -538,10 +538,10 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                 EiV          = EiV + em;
                 EiV          = EiV * tc;
                 // origin of the shadow ray and of the extension ray alike (:805, :922), tmin 1e-6 for both
-                f.rayO[px]   = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, 0.000001f);
-                f.shD[px]    = make_float4(vLight.x, vLight.y, vLight.z, 0.0f);
-                f.eiVis[px]  = make_float4(EiV.x, EiV.y, EiV.z, colorw);
-                f.contrib[(size_t)bounce * f.npix + px] = make_float4(EiO.x, EiO.y, EiO.z, colorw);
+                st_nt(f.rayO + px, make_float4(hitPoint.x, hitPoint.y, hitPoint.z, 0.000001f));
+                st_nt(f.shD + px, make_float4(vLight.x, vLight.y, vLight.z, 0.0f));
+                st_nt(f.eiVis + px, make_float4(EiV.x, EiV.y, EiV.z, colorw));
+                st_nt(f.contrib + ((size_t)bounce * f.npix + px), make_float4(EiO.x, EiO.y, EiO.z, colorw));
                 f.nvert[px]  = (uint8_t)(nv0 | (bounce + 1u));
                 shadowQ      = true;
 
@@ -568,16 +568,16 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                 }
                 if(alive)
                 {
-                    f.rayD[px] = make_float4(Rn.x, Rn.y, Rn.z, 1.0f);
-                    f.thr[px]  = make_float4(throughput.x, throughput.y, throughput.z, p);
+                    st_nt(f.rayD + px, make_float4(Rn.x, Rn.y, Rn.z, 1.0f));
+                    st_nt(f.thr + px, make_float4(throughput.x, throughput.y, throughput.z, p));
                     nextQ      = true;
                 }
             }
         }
         const uint32_t si = block_push(shadowQ, countShadow, pushLds);
-        if(shadowQ) queueShadow[si] = px;
+        if(shadowQ) st_nt(queueShadow + si, px);
         const uint32_t ni = block_push(nextQ, countNext, pushLds);
-        if(nextQ) queueNext[ni] = px;
+        if(nextQ) st_nt(queueNext + ni, px);
     }
 }
 
