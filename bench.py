@@ -216,6 +216,12 @@ def main():
                     "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(nn, 2), "tris_per_ray": round(nt, 2),
                     "rays_per_launch": round(nrays / launches, 1), "ms_per_launch": round(ms_launch, 4),
                     "launches": launches,
+                    "traffic_rate": None if not traffic else {
+                        "GB/s": round(traffic / (ms_launch * 1e-3) / 1e9, 1),
+                        "frac_of_peak": round(traffic / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "what": "bytes that left L2 per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json; "
+                                "Infinity-Cache hits included) / this run's launch time: the scene's BVH lives in "
+                                "L2 / Infinity Cache, so the algorithmic rate above can exceed the HBM peak"},
                     "note": "ms_per_launch is wall time of a launch on its own stream while the other in-flight "
                             "iterations' kernels share the GPU (pipelined passes), so it understates the kernel's "
                             "stand-alone rate",
