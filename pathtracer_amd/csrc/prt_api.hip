@@ -22,7 +22,9 @@ static std::string g_createError;
 
 static constexpr uint32_t kStatWords    = 28;
 static constexpr uint32_t kCounterWords = 256;
-static constexpr uint32_t kMaxBounces   = 24;  // UI cap is 10 (vkContext.cpp:266)
+// UI cap is 10 (vkContext.cpp:266). The shader indexes scrambleArray[16] with 1 + bounce (pathRT.rgen:635-642, :703) and
+// takes Sobol dimensions 4 + 4*bounce .. +3 of the 64 kept here: both are defined up to 14 bounces.
+static constexpr uint32_t kMaxBounces   = 14;
 static constexpr int      kMaxPipes     = 8;
 
 // Per-pass state: one iteration (pass) is in flight per pipe, each on its own HIP stream.

@@ -146,6 +146,30 @@ def test_path_and_ao_bit_exact(po, case):
         _render_both(po, scenes.random_soup(3000), 128, 96, 1, [0, 2, 3], ao_rays=7, ao_length=2.5)
 
 
+@pytest.mark.parametrize("W,H,bounces,n,batch", [(1, 1, 3, 5, 4), (7, 3, 0, 3, 8), (67, 45, 10, 9, 4), (130, 1, 2, 17, 8),
+                                                 (33, 31, 14, 2, 2)])
+def test_odd_sizes_and_extreme_bounces_batched(po, W, H, bounces, n, batch):
+    """Image sizes that are no multiple of a wave, a block or a tile, zero bounces, the UI's maximum (10) and the
+    library's maximum (14: the shader's scrambleArray[16] ends there) number of bounces, rendered through prt_render (several iterations per pass): image, primary
+    hit ids of the last iteration and ray count against the oracle."""
+    sc = scenes.cornell_box()
+    o, ctx = _pair(po, sc, W, H, 5, 0)
+    ctx.set_iteration_batch(batch)
+    ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=bounces, light_area=0.3))
+    ctx.reset_stats()
+    ctx.render(capi.MODE_PATH, 1, n, 1)
+    acc, ids, rays = np.zeros((H, W, 4), np.float32), None, 0
+    for it in range(1, n + 1):
+        acc, ids, r = o.render(uniforms.make_uniforms(sc, W, H, bounces=bounces, light_area=0.3, iteration=it), W, H,
+                               capi.MODE_PATH, accum=acc, want_ids=True)
+        rays += r
+    assert ctx.read_accum().tobytes() == acc.tobytes()
+    assert (ctx.read_hit_ids() == ids).all() and ctx.stats().rays == rays and ctx.stats().iterations == n
+    with pytest.raises(capi.PrtError):
+        ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=15))
+    ctx.close()
+
+
 def test_pipelined_iterations_equal_sequential():
     """Iterations in flight on several streams (prt_set_pipeline_depth) sum in iteration order: bit-identical."""
     sc = scenes.conference_room(detail=0.4)
