@@ -170,6 +170,65 @@ def test_odd_sizes_and_extreme_bounces_batched(po, W, H, bounces, n, batch):
     ctx.close()
 
 
+def _degenerate_soup():
+    """Triangle soup with what real assets contain: zero-area triangles (repeated corner, collinear corners), exact
+    duplicates (closest-hit tie -> lower primitive id), a needle thinner than a float ulp at its position, and a copy of
+    part of the soup 4000 units away (large coordinates next to small ones)."""
+    from pathtracer_amd.scenes import MeshBuilder, make_material
+
+    base = scenes.random_soup(600, seed=11)
+    P = base["vertices"]["p"][base["indices"]].reshape(-1, 3, 3).astype(np.float32)
+    extra = [P[:40].copy(),  # duplicates
+             np.stack([P[40:60, 0], P[40:60, 0], P[40:60, 1]], axis=1),  # repeated corner
+             np.stack([P[60:80, 0], (P[60:80, 0] + P[60:80, 1]) * 0.5, P[60:80, 1]], axis=1),  # collinear
+             np.array([[[0.0, 0.0, 0.0], [3.0, 0.0, 0.0], [1.5, 1e-9, 0.0]]], np.float32),  # needle
+             P[:100] + np.float32(4000.0)]
+    mb = MeshBuilder()
+    mb.add(np.concatenate([P] + extra), 0)
+    sc = mb.finish([make_material()])
+    sc["name"], sc["camera"], sc["light"] = "degenerate", base["camera"], base["light"]
+    return sc
+
+
+@pytest.mark.parametrize("case", ["ao_1ray", "ao_256rays", "aa8_b10", "rr_b14", "table_batched", "degenerate", "one_triangle"])
+def test_more_edge_cases_through_prt_render(po, case):
+    W, H, mode, n, flags, kw, table = 37, 29, capi.MODE_PATH, 5, 0, dict(bounces=3), None
+    sc = scenes.cornell_box()
+    if case == "ao_1ray":
+        mode, n, kw = capi.MODE_AO, 2, dict(ao_rays=1, ao_length=0.001)
+    elif case == "ao_256rays":
+        mode, n, kw = capi.MODE_AO, 1, dict(ao_rays=256, ao_length=5.0)
+    elif case == "aa8_b10":
+        n, kw = 3, dict(bounces=10, aa_rays=8, filter_radius=4.0, light_area=0.3)
+    elif case == "rr_b14":
+        flags, kw = capi.FLAG_RUSSIAN_ROULETTE, dict(bounces=14, light_area=0.3)
+    elif case == "table_batched":
+        table = np.random.default_rng(5).integers(0, 2**32, (32, H * W), dtype=np.uint64).astype(np.uint32)
+        n = 7
+    elif case == "degenerate":
+        sc, W, H, n = _degenerate_soup(), 96, 64, 3
+    elif case == "one_triangle":
+        sc, W, H = scenes.random_soup(1, seed=2, extent=0.1, size=2.0), 64, 48
+    o, ctx = _pair(po, sc, W, H, 4, flags)
+    if table is not None:
+        ctx.upload_scrambles(table)
+        o.set_scramble_table(table, W, H)
+    ctx.set_iteration_batch(4)
+    ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, **kw))
+    ctx.reset_stats()
+    ctx.render(mode, 1, n, 1)
+    acc, ids, rays = np.zeros((H, W, 4), np.float32), None, 0
+    for it in range(1, n + 1):
+        acc, ids, r = o.render(uniforms.make_uniforms(sc, W, H, iteration=it, **kw), W, H, mode, accum=acc, flags=flags,
+                               want_ids=True)
+        rays += r
+    g = ctx.read_accum()
+    nd = int((g.view(np.uint32) != acc.view(np.uint32)).any(axis=-1).sum())
+    assert nd == 0, f"{nd} pixels differ"
+    assert (ctx.read_hit_ids() == ids).all() and ctx.stats().rays == rays
+    ctx.close()
+
+
 def test_pipelined_iterations_equal_sequential():
     """Iterations in flight on several streams (prt_set_pipeline_depth) sum in iteration order: bit-identical."""
     sc = scenes.conference_room(detail=0.4)
