@@ -208,7 +208,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(kname.split(" ")[0], {}).get("hbm_bytes_per_launch")
+                t = json.load(open(pmc)).get(kname.split(" ")[0], {})
+                traffic = t.get("hbm_bytes_per_launch")
+                if t.get("hbm_bytes_per_ray"):  # counters were taken at another launch size: scale to this run's
+                    traffic = int(t["hbm_bytes_per_ray"] * nrays / launches)
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,

@@ -301,11 +301,11 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
             if(nb >= 1 && nb <= 16) c->gridShade = (uint32_t)nb * (uint32_t)c->numCU;
         }
         if(const char* fe = getenv("PRT_FUSE")) c->fuse = atoi(fe) != 0;
-        // default batch: enough iterations to put ~16 M pixels into a pass (8 at 1080p, 2 at 4K), at most 8
+        // default batch: enough iterations to put ~32 M pixels into a pass (16 at 1080p, 4 at 4K), at most 16
         {
-            const uint64_t target = 16ull << 20;
+            const uint64_t target = 32ull << 20;
             uint64_t       b      = (target + c->npix / 2) / c->npix;
-            c->batch              = (uint32_t)(b < 1 ? 1 : (b > 8 ? 8 : b));
+            c->batch              = (uint32_t)(b < 1 ? 1 : (b > 16 ? 16 : b));
             if(const char* be = getenv("PRT_BATCH"))
             {
                 const int v = atoi(be);
@@ -1017,13 +1017,9 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
         {
             const uint32_t nsub = n - k < c->batch ? n - k : c->batch;
             c->ubo.iteration    = first + k * stride;
-            // big passes leave little tail to fill: two in flight are enough, a third only adds contention (measured)
-            static const bool rotAll = getenv("PRT_ROT_ALL") != nullptr;  // measurement only
-            const int rot = ((uint64_t)c->npix * nsub >= (12ull << 20) && c->nPipes > 2 && !rotAll) ? 2 : c->nPipes;
-            if(c->nextPipe >= rot) c->nextPipe = 0;
-            const int rc = render_path_pass(c, c->nextPipe, 0, nsub, stride);
+            const int rc        = render_path_pass(c, c->nextPipe, 0, nsub, stride);
             if(rc) return rc;
-            c->nextPipe = (c->nextPipe + 1) % rot;
+            c->nextPipe = (c->nextPipe + 1) % c->nPipes;
             c->iterations += nsub;
             k += nsub;
         }

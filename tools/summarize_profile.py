@@ -11,7 +11,7 @@ def short(n):
     n = n.replace("void ", "")
     return n.split("(")[0]
 
-out = [f"# rocprofv3 summary ({tag}) — `python3 bench.py --steps 16 --warmup 8 --no-cpu-baseline --pipes 1` on one MI355X (one pass in flight, so that a kernel's trace duration is its own; every path-tracing launch covers 8 iterations = 16.6 M pixels)\n"]
+out = [f"# rocprofv3 summary ({tag}) — `python3 bench.py --steps 32 --warmup 16 --no-cpu-baseline --pipes 1` on one MI355X (one pass in flight, so that a kernel's trace duration is its own; every path-tracing launch covers 16 iterations = 33.2 M pixels)\n"]
 db = sqlite3.connect(os.path.join(G, "prof_trace", "trace_results.db"))
 out.append("## `rocprofv3 --kernel-trace --stats` (top kernels; durations in microseconds)\n")
 out.append("| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|")
@@ -58,8 +58,18 @@ out.append("### raw SQ counters (sum over launches)\n")
 for k in ["prt::k_shadow_extend<false>", "prt::k_extend<false>", "prt::k_shadow<false>", "prt::k_shade"]:
     if k in sq: out.append(f"* `{k}`: " + ", ".join(f"{c}={v:.4g}" for c, v in sorted(sq[k].items())))
 open(os.path.join(P, f"{tag}_rocprof_summary.md"), "w").write("\n".join(out) + "\n")
-json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 bj = os.path.join(G, "prof_trace.json")
+if os.path.exists(bj):
+    # the launch size the counters belong to (bench.py scales the traffic to its own launch size with it)
+    try:
+        r = json.load(open(bj))["roofline"]
+        k = r["kernel"].split(" ")[0]
+        if k in traffic:
+            traffic[k]["rays_per_launch"] = r["standalone"]["rays_per_launch"]
+            traffic[k]["hbm_bytes_per_ray"] = round(traffic[k]["hbm_bytes_per_launch"] / r["standalone"]["rays_per_launch"], 2)
+    except Exception as e:
+        print("no launch size:", e)
+json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 if os.path.exists(bj):
     open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w").write(open(bj).read())
 print("\n".join(out))
