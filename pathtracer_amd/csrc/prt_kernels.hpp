@@ -105,10 +105,10 @@ PRT_DEV uint32_t block_push(bool pred, uint32_t* counter, uint32_t* lds /*[8]*/)
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-PRT_DEV uint32_t wave_fetch(uint32_t* workCtr)
+PRT_DEV uint32_t wave_fetch(uint32_t* workCtr, uint32_t n)
 {
     uint32_t base = 0;
-    if((threadIdx.x & 63) == 0) base = atomicAdd(workCtr, 64u);
+    if((threadIdx.x & 63) == 0) base = atomicAdd(workCtr, n);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 }
 
@@ -699,11 +699,16 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
     const int           numAO   = ubo->numAOrays;
     const float         aoLen   = ubo->aoRayLength;
     uint32_t            nrays   = 0;
-    for(;;)
+    // 256 pixels per work-counter atomic (a device-scope atomic is a round trip to the memory side), 64 at a time
+    for(uint32_t sub = 4u, base0 = 0u;; ++sub)
     {
-        const uint32_t base = wave_fetch(workCtr);
-        if(base >= count) break;
-        const uint32_t px = base + lane;
+        if(sub == 4u)
+        {
+            base0 = wave_fetch(workCtr, 256u);
+            if(base0 >= count) break;
+            sub = 0u;
+        }
+        const uint32_t px = base0 + sub * 64u + lane;
         if(px < count)
         {
             const float4   hq   = f.hit[px];
