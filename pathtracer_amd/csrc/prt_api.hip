@@ -1015,7 +1015,9 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
         }
         while(n - k >= 2)
         {
-            const uint32_t nsub = n - k < c->batch ? n - k : c->batch;
+            uint32_t nsub = n - k < c->batch ? n - k : c->batch;
+            if((uint64_t)c->npix * nsub >= (1ull << 31)) nsub = (uint32_t)(((1ull << 31) - 1) / c->npix);  // 32-bit pixel ids
+            if(nsub < 2) break;
             c->ubo.iteration    = first + k * stride;
             const int rc        = render_path_pass(c, c->nextPipe, 0, nsub, stride);
             if(rc) return rc;
