@@ -19,6 +19,8 @@
 //   pow(x,5)      = ((x*x)*(x*x))*x ; pow(x,4) = (x*x)*(x*x) ; pow(x,3) = (x*x)*x ; pow(x,2) = x*x
 #include "oracle.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -428,6 +430,7 @@ struct RayPre
     // slab test
     float onear[3], ofar[3], rdn[3], rdf[3];
     int   neg[3];
+    float amax;  // max(|scene|, |origin|): scale of the pads
 };
 
 inline void rayPrepare(const orc_scene& sc, const float o[3], const float d[3], RayPre& r)
@@ -465,6 +468,7 @@ inline void rayPrepare(const orc_scene& sc, const float o[3], const float d[3], 
     for(int k = 0; k < 3; ++k)
         amax = gmax(amax, gabs(o[k]));
     const float pad = 3.814697265625e-06f * amax;  // 64 * 2^-24
+    r.amax          = amax;
     for(int k = 0; k < 3; ++k)
     {
         float dk = d[k];
@@ -541,6 +545,20 @@ inline bool triTest(const RayPre& r, const float* p0, const float* p1, const flo
     const float t   = T * rcp;
     if(!(t > tmin && t < tmax))
         return false;
+    // A ray that grazes the triangle's plane can pass the edge tests with weights U, V, W that are rounding noise, so
+    // that o + t*d lies outside the triangle; no conservative box test can be made to keep such a "hit". A hit
+    // therefore has to put the hit point, rebuilt from the same weights (depth along the major axis = weighted vertex
+    // depths; minor axes = shear * depth), within the triangle's extent along the two minor axes, grown by a quarter
+    // of the pad of the slab test (definition shared with the HIP kernel).
+    {
+        const float hpad = 9.5367431640625e-07f * r.amax;  // 16 * 2^-24
+        const float zh   = ((U * A[r.kz] + V * B[r.kz]) + W * C[r.kz]) * rcp;
+        const float xh = r.Sx * zh, yh = r.Sy * zh;
+        if(xh < gmin(gmin(A[r.kx], B[r.kx]), C[r.kx]) - hpad || xh > gmax(gmax(A[r.kx], B[r.kx]), C[r.kx]) + hpad)
+            return false;
+        if(yh < gmin(gmin(A[r.ky], B[r.ky]), C[r.ky]) - hpad || yh > gmax(gmax(A[r.ky], B[r.ky]), C[r.ky]) + hpad)
+            return false;
+    }
     tOut = t;
     uOut = V * rcp;
     vOut = W * rcp;
@@ -1023,8 +1041,27 @@ void aoPixel(PixelCtx& cx, uint32_t px, uint32_t py, float* Eio, uint32_t* hitId
 // ------------------------------------------------------------------------------------------------
 // pathRT.rgen main — pathRT.rgen:621-974
 // ------------------------------------------------------------------------------------------------
+// ORC_DEBUG_PIXEL="x,y": print every ray pathPixel traces for that pixel and what it hit (test infrastructure only)
+static bool debugPixel(uint32_t px, uint32_t py)
+{
+    static int dx = -2, dy = -2;
+    if(dx == -2)
+    {
+        dx = dy = -1;
+        if(const char* e = getenv("ORC_DEBUG_PIXEL")) sscanf(e, "%d,%d", &dx, &dy);
+    }
+    return (int)px == dx && (int)py == dy;
+}
+static void debugRay(const char* what, int aa, int bounce, const float* o, float tmin, const float* d, float tmax,
+                     uint32_t prim, float t)
+{
+    fprintf(stderr, "ORC %s aa %d bounce %d o %a %a %a tmin %a d %a %a %a tmax %a -> prim %u t %a\n", what, aa, bounce,
+            o[0], o[1], o[2], tmin, d[0], d[1], d[2], tmax, prim, t);
+}
+
 void pathPixel(PixelCtx& cx, uint32_t px, uint32_t py, float* Eio, uint32_t* hitId)
 {
+    const bool dbg = debugPixel(px, py);
     const orc_scene&    sc  = cx.sc;
     const prt_uniforms& ubo = cx.ubo;
     const bool          literal = (cx.flags & ORC_FLAG_LITERAL) != 0;
@@ -1079,6 +1116,7 @@ void pathPixel(PixelCtx& cx, uint32_t px, uint32_t py, float* Eio, uint32_t* hit
         a3(Rd, d);
         orc_hit payload = traceClosest(sc, o, tmin, d, tmax, cx.brute);
         cx.rays++;
+        if(dbg) debugRay("primary", aaRay, 0, o, tmin, d, tmax, payload.prim, payload.t);
         if(hitId)
             *hitId = payload.prim;
         if(payload.prim == 0xffffffffu)
@@ -1184,6 +1222,7 @@ void pathPixel(PixelCtx& cx, uint32_t px, uint32_t py, float* Eio, uint32_t* hit
             a3(vLight, d);
             const bool isShadowed = traceAny(sc, o, tmin, d, tmax, cx.brute);
             cx.rays++;
+            if(dbg) debugRay("shadow", aaRay, bounce, o, tmin, d, tmax, isShadowed ? 1u : 0xffffffffu, 0.0f);
             if(!isShadowed)
             {
                 const vec4  l2 = vec4{ubo.lightTransform[8], ubo.lightTransform[9], ubo.lightTransform[10], 0.0f};
@@ -1303,6 +1342,7 @@ void pathPixel(PixelCtx& cx, uint32_t px, uint32_t py, float* Eio, uint32_t* hit
             a3(Rd, d);
             payload = traceClosest(sc, o, tmin, d, tmax, cx.brute);
             cx.rays++;
+            if(dbg) debugRay("bounce", aaRay, bounce, o, tmin, d, tmax, payload.prim, payload.t);
             if(payload.prim == 0xffffffffu)
                 break;
         }

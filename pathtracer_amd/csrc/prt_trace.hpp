@@ -140,7 +140,8 @@ PRT_DEV void ray_prepare(const BvhView& bvh, f3 o, float tmin, f3 d, float tmax,
 #undef PRT_SLAB_SETUP
 }
 
-PRT_DEV bool tri_test(const RayCtx& r, float4 q0, float4 q1, float4 q2, float& tOut, float& uOut, float& vOut)
+PRT_DEV bool tri_test(const RayCtx& r, float sceneAbs, float4 q0, float4 q1, float4 q2, float& tOut, float& uOut,
+                      float& vOut)
 {
     int kx = r.kz + 1; if(kx == 3) kx = 0;
     int ky = kx + 1; if(ky == 3) ky = 0;
@@ -179,6 +180,25 @@ PRT_DEV bool tri_test(const RayCtx& r, float4 q0, float4 q1, float4 q2, float& t
     const float t   = T * rcp;
     if(!(t > r.tmin && t < r.tmax))
         return false;
+    // A ray that grazes the triangle's plane (|d.n| < ~1e-3 |d|) can pass the edge tests with weights U, V, W that are
+    // rounding noise: the hit point o + t*d then lies outside the triangle, and no conservative box test can be made
+    // to keep such a hit. So it is not one: along the two minor axes the hit point, rebuilt from the same weights
+    // (depth along the major axis = the weighted vertex depths, a convex combination and hence always inside the
+    // triangle's extent; minor axes = shear * depth), has to lie within the triangle's extent grown by a quarter of
+    // the pad of the box test. Found by tools/fuzz_parity.py (one pixel in ~10^8).
+    {
+        float amax = sceneAbs;
+        amax       = gmax(amax, gabs(r.ox));
+        amax       = gmax(amax, gabs(r.oy));
+        amax       = gmax(amax, gabs(r.oz));
+        const float hpad = 9.5367431640625e-07f * amax;  // 16 * 2^-24
+        const float zh   = ((U * Akz + V * Bkz) + W * Ckz) * rcp;
+        const float xh = r.Sx * zh, yh = r.Sy * zh;
+        const float Akx = sel3(Ax_, Ay_, Az_, kx), Bkx = sel3(Bx_, By_, Bz_, kx), Ckx = sel3(Cx_, Cy_, Cz_, kx);
+        if(xh < gmin(gmin(Akx, Bkx), Ckx) - hpad || xh > gmax(gmax(Akx, Bkx), Ckx) + hpad) return false;
+        const float Aky = sel3(Ax_, Ay_, Az_, ky), Bky = sel3(Bx_, By_, Bz_, ky), Cky = sel3(Cx_, Cy_, Cz_, ky);
+        if(yh < gmin(gmin(Aky, Bky), Cky) - hpad || yh > gmax(gmax(Aky, Bky), Cky) + hpad) return false;
+    }
     tOut = t;
     uOut = V * rcp;
     vOut = W * rcp;
@@ -317,7 +337,7 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
 #endif
         float tt, uu, vv;
         if(INSTR) tc.tris++;
-        if(tri_test(r, a, b, c, tt, uu, vv))
+        if(tri_test(r, bvh.sceneAbs, a, b, c, tt, uu, vv))
         {
             const uint32_t p = (uint32_t)__float_as_int(a.w);
             if(ANY)
