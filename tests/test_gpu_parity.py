@@ -115,6 +115,24 @@ def test_trace_edge_cases(po):
     ctx.close()
 
 
+def test_grazing_self_hits(po):
+    """Rays that leave a thin triangle almost in its plane (tests/helpers/grazing.py): closest and any-hit results of
+    the GPU's BVH4 traversal equal the oracle's brute force over all triangles (hit definition)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+    import grazing
+
+    sc = grazing.strip_scene()
+    o, ctx = _pair(po, sc, 16, 16)
+    for seed in (1, 2, 3):
+        rays = grazing.grazing_rays(capi.RAY_DTYPE, sc, 20000, seed)
+        g, b = ctx.trace(rays), o.trace_closest(rays, brute=True)
+        assert g.tobytes() == b.tobytes()
+        assert ((ctx.trace(rays, any_hit=True)["prim"] != MISS) == (o.trace_any(rays, brute=True) == 1)).all()
+    ctx.close()
+
+
 def test_config0_cornell_ao_512(po):
     """BASELINE.json configs[0]: Cornell box 512x512, AO mode, 16 rays."""
     _render_both(po, scenes.cornell_box(), 512, 512, capi.MODE_AO, [1], seed=1, ao_rays=16, ao_length=1.0)
