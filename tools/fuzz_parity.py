@@ -12,7 +12,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0, case = time.time(), 0
 while time.time() - t0 < budget:
     case += 1
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 5)
     if kind == 0:
         sc = scenes.random_soup(int(rng.integers(1, 6000)), seed=int(rng.integers(1 << 30)), extent=float(rng.uniform(0.5, 8)),
                                 size=float(rng.uniform(0.05, 2.0)))
@@ -21,6 +21,16 @@ while time.time() - t0 < budget:
     elif kind == 2:
         sc = scenes.conference_room(seed=int(rng.integers(1 << 30)), detail=float(rng.uniform(0.5, 1.0) if big else rng.uniform(0.15, 0.5)),
                                     textured=bool(rng.integers(0, 2)))
+    elif kind == 4:  # soup with duplicates, zero-area triangles and a far copy
+        base = scenes.random_soup(int(rng.integers(3, 800)), seed=int(rng.integers(1 << 30)), size=float(rng.uniform(0.01, 1.0)))
+        P = base["vertices"]["p"][base["indices"]].reshape(-1, 3, 3).astype(np.float32)
+        m = max(1, len(P) // 4)
+        mb = scenes.MeshBuilder()
+        mb.add(np.concatenate([P, P[:m], np.stack([P[:m, 0], P[:m, 0], P[:m, 1]], axis=1),
+                               np.stack([P[:m, 0], (P[:m, 0] + P[:m, 1]) * 0.5, P[:m, 1]], axis=1),
+                               P[:m] + np.float32(rng.uniform(100, 5000))]), 0)
+        sc = mb.finish([scenes.make_material()])
+        sc["name"], sc["camera"], sc["light"] = "degenerate", base["camera"], base["light"]
     else:
         sc = scenes.sponza_scale(seed=int(rng.integers(1 << 30)), detail=float(rng.uniform(0.3, 0.7) if big else rng.uniform(0.05, 0.2)))
     W, H = (int(rng.integers(200, 640)), int(rng.integers(150, 400))) if big else (int(rng.integers(1, 200)), int(rng.integers(1, 150)))
@@ -52,6 +62,10 @@ while time.time() - t0 < budget:
     ctx = capi.Context(W, H)
     ctx.set_scene(sc); ctx.set_seed(seed); ctx.build_accel(); ctx.set_flags(flags)
     ctx.set_pipeline_depth(depth); ctx.set_iteration_batch(batch)
+    if rng.random() < 0.2:  # the reference's explicit 32-layer scramble image instead of the hash
+        table = rng.integers(0, 2 ** 32, (32, H * W), dtype=np.uint64).astype(np.uint32)
+        ctx.upload_scrambles(table)
+        o.set_scramble_table(table, W, H)
     ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, **kw))
     ctx.reset_stats()
     ctx.render(mode, first, n, stride)
