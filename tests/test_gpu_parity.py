@@ -458,6 +458,25 @@ def test_full_size_primary_hit_ids_bit_exact(po, conference_full):
     assert (gid != MISS).all()  # closed room
 
 
+def test_full_size_image_bit_exact(po, conference_full):
+    """BASELINE.json's metric configuration itself — 328 k triangles, 1920x1080, 5 bounces — for three iterations
+    through the batched prt_render: the whole accumulation image and the ray count against the oracle."""
+    sc, ctx = conference_full
+    W, H, B = 1920, 1080, 5
+    ctx.clear_accum()
+    ctx.reset_stats()
+    ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=B))
+    ctx.render(capi.MODE_PATH, 1, 3, 1)
+    g = ctx.read_accum()
+    o = po.Oracle(sc, seed=2)
+    acc, rays = np.zeros((H, W, 4), np.float32), 0
+    for it in (1, 2, 3):
+        acc, _, r = o.render(uniforms.make_uniforms(sc, W, H, bounces=B, iteration=it), W, H, 0, accum=acc)
+        rays += r
+    nd = int((g.view(np.uint32) != acc.view(np.uint32)).any(axis=-1).sum())
+    assert nd == 0 and ctx.stats().rays == rays, f"{nd} of {W * H} pixels differ, rays {ctx.stats().rays} vs {rays}"
+
+
 def test_full_size_properties(conference_full):
     sc, ctx = conference_full
     W, H, B = 1920, 1080, 5
