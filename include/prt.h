@@ -192,6 +192,19 @@ int prt_trace(prt_context* ctx, const prt_ray* rays, size_t n, int any_hit, prt_
  * the context's stream; *ms_out receives the kernel time. */
 int prt_trace_device(prt_context* ctx, const void* rays_dev, size_t n, int any_hit, void* hits_dev, float* ms_out);
 
+/* prt_trace_device for callers that cannot allocate. No counterpart in the reference: it exists for callers that
+ * must not call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid allocation).
+ * It calls no hipMalloc / hipFree / event or stream creation; the one piece of scratch the persistent traversal
+ * kernel needs (its work-fetch cursor) is a 256-byte file-scope __device__ array of the library, one copy per GPU,
+ * held until the process ends. Rays/hits as in prt_trace_device (2 x float4 per ray, 1 x float4 per hit, device
+ * memory of the caller). Asynchronous: the launch is enqueued on `stream` (a hipStream_t; NULL = the context's own
+ * stream, then prt_sync waits for it) and not timed. n above PRT_NOALLOC_MAX_RAYS is refused with PRT_E_LIMIT.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams or contexts
+ * without ordering between them) race on the cursor; serialise them. */
+#define PRT_NOALLOC_MAX_RAYS 0x40000000u /* 2^30 rays per call */
+int prt_trace_device_noalloc(prt_context* ctx, const void* rays_dev, size_t n, int any_hit, void* hits_dev,
+                             void* stream);
+
 /* Inspection of the acceleration structure (nodes_out: bvh_nodes entries, order_out: one per triangle). */
 int prt_read_bvh(prt_context* ctx, prt_bvh_node* nodes_out, uint32_t* order_out);
 /* The 64 x 32 Sobol matrix words in use (sobol.h:28-33 restricted to what the path reads). */

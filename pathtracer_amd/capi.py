@@ -21,7 +21,7 @@ EXPORTS = [
     "prt_create", "prt_destroy", "prt_last_error", "prt_set_scene", "prt_build_accel", "prt_set_scramble_seed",
     "prt_upload_scrambles", "prt_set_uniforms", "prt_set_flags", "prt_render_iteration", "prt_render", "prt_sync",
     "prt_clear_accum", "prt_read_accum", "prt_device_accum_ptr", "prt_bind_accum", "prt_postprocess",
-    "prt_read_hit_ids", "prt_get_stats", "prt_reset_stats", "prt_trace", "prt_trace_device", "prt_read_bvh",
+    "prt_read_hit_ids", "prt_get_stats", "prt_reset_stats", "prt_trace", "prt_trace_device", "prt_trace_device_noalloc", "prt_read_bvh",
     "prt_read_sobol", "prt_set_profiling", "prt_set_profiling_mask", "prt_get_profile", "prt_set_pipeline_depth", "prt_get_pipeline_depth",
     "prt_update_vertices", "prt_refit_accel", "prt_write_accum", "prt_set_iteration_batch", "prt_get_iteration_batch",
     "prt_group_create", "prt_group_destroy", "prt_group_last_error", "prt_group_size", "prt_group_uses_rccl",
@@ -95,6 +95,7 @@ def lib():
         L.prt_reset_stats.argtypes = [vp]
         L.prt_trace.argtypes = [vp, vp, sz, i32, vp]
         L.prt_trace_device.argtypes = [vp, vp, sz, i32, vp, C.POINTER(C.c_float)]
+        L.prt_trace_device_noalloc.argtypes = [vp, vp, sz, i32, vp, vp]
         L.prt_read_bvh.argtypes = [vp, vp, vp]
         L.prt_read_sobol.argtypes = [vp, vp]
         L.prt_set_profiling.argtypes = [vp, i32]
@@ -293,6 +294,10 @@ class Context:
         self._chk(self.L.prt_trace_device(self.h_, C.c_void_p(rays_ptr), n, 1 if any_hit else 0,
                                           C.c_void_p(hits_ptr), C.byref(ms)))
         return ms.value
+
+    def trace_device_noalloc(self, rays_ptr, n, hits_ptr, any_hit=False, stream=None):
+        self._chk(self.L.prt_trace_device_noalloc(self.h_, C.c_void_p(rays_ptr), n, 1 if any_hit else 0,
+                                                  C.c_void_p(hits_ptr), C.c_void_p(stream)))
 
     def read_bvh(self):
         s = self.stats()

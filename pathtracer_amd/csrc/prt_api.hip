@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,32 @@
 using namespace prt;
 
 static std::string g_createError;
+
+// ---- scratch of the allocation-free entry point (prt_trace_device_noalloc) ------------------------------------
+// The persistent traversal kernel needs one piece of device memory besides its inputs and outputs: the work-fetch
+// cursor its waves pull ray chunks from (prt_trace_device takes it from hipMalloc'ed context memory). Here it is a
+// file-scope __device__ array, so a caller that must not allocate (HIP graph capture, serving loops) needs no
+// workspace. 256 bytes per GPU, held until the process ends. In host code `scratch` is only a stand-in for the
+// symbol: its device address is asked for once per device (scratch_for_device) and only that pointer is used.
+#define PRT_NOALLOC_SCRATCH_BYTES 256
+static __device__ __align__(256) uint32_t scratch[PRT_NOALLOC_SCRATCH_BYTES / 4];
+static constexpr int kMaxDevices = 64;
+static uint32_t*     g_scratchPtr[kMaxDevices] = {};  // device address of `scratch` on every GPU the library has used
+static std::mutex    g_scratchMutex;
+
+// with `device` current: the address of this GPU's copy of `scratch` (each GPU holds its own copy of the array)
+static hipError_t scratch_for_device(int device)
+{
+    if(device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if(g_scratchPtr[device]) return hipSuccess;
+    uint32_t*        ptr = nullptr;
+    const hipError_t e   = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if(e != hipSuccess) return e;
+    if(!ptr) return hipErrorInvalidSymbol;
+    g_scratchPtr[device] = ptr;
+    return hipSuccess;
+}
 
 static constexpr uint32_t kStatWords    = 28;
 static constexpr uint32_t kCounterWords = 256;
@@ -275,6 +302,7 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
     c->h           = height;
     c->npix        = width * height;
     hipError_t e   = hipSetDevice(device);
+    if(e == hipSuccess) e = scratch_for_device(device);  // set-up of prt_trace_device_noalloc, once per GPU
     if(e == hipSuccess) e = hipStreamCreate(&c->stream);
     hipDeviceProp_t prop;
     if(e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
@@ -773,6 +801,19 @@ struct ProfScope
     }
 };
 
+static void fill_bvh_view(const prt_context* c, BvhView& b)
+{
+    b.nodes    = c->dNodes;
+    b.tris     = c->dTris;
+    b.root     = c->root;
+    b.sceneAbs = c->sceneAbs;
+    for(int k = 0; k < 3; ++k)
+    {
+        b.qmin[k]   = c->grid.qmin[k];
+        b.qscale[k] = c->grid.qscale[k];
+    }
+}
+
 static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& f, uint32_t nsub = 1, uint32_t iterStride = 1)
 {
     sc.stri         = c->dShadeTris;
@@ -787,15 +828,7 @@ static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& 
     sc.ntex         = c->ntex;
     sc.seed         = c->seed;
     sc.ntri         = c->ntri;
-    sc.bvh.nodes    = c->dNodes;
-    sc.bvh.tris     = c->dTris;
-    sc.bvh.root     = c->root;
-    sc.bvh.sceneAbs = c->sceneAbs;
-    for(int k = 0; k < 3; ++k)
-    {
-        sc.bvh.qmin[k]   = c->grid.qmin[k];
-        sc.bvh.qscale[k] = c->grid.qscale[k];
-    }
+    fill_bvh_view(c, sc.bvh);
     f.w       = c->w;
     f.h       = c->h;
     f.npix    = c->npix * nsub;
@@ -1256,6 +1289,37 @@ int prt_trace_device(prt_context* c, const void* rays, size_t n, int any, void* 
     (void)hipEventDestroy(e1);
     HIPCHK(c, e);
     if(ms) *ms = t;
+    return PRT_OK;
+}
+
+// prt_trace_device without any allocation: no hipMalloc / hipFree / event or stream creation; the kernel's work-fetch
+// cursor is this GPU's copy of the file-scope `scratch` array. Asynchronous on `stream` (NULL: the context's).
+int prt_trace_device_noalloc(prt_context* c, const void* rays, size_t n, int any, void* hits, void* stream)
+{
+    if(!c || !rays || !hits) return PRT_E_INVALID;
+    if(!c->haveAccel) return fail(c, PRT_E_NOSCENE, "prt_trace_device_noalloc: no acceleration structure");
+    if(c->accelStale)
+        return fail(c, PRT_E_NOSCENE, "prt_trace_device_noalloc: vertices changed, call prt_refit_accel or prt_build_accel");
+    if(n > PRT_NOALLOC_MAX_RAYS)
+        return fail(c, PRT_E_LIMIT, "prt_trace_device_noalloc: %zu rays, the limit of this entry point is %u", n,
+                    (unsigned)PRT_NOALLOC_MAX_RAYS);
+    if(c->device < 0 || c->device >= kMaxDevices || !g_scratchPtr[c->device])
+        return fail(c, PRT_E_HIP, "prt_trace_device_noalloc: scratch of device %d was not set up", c->device);
+    HIPCHK(c, hipSetDevice(c->device));
+    if(n == 0) return PRT_OK;
+    uint32_t*   work = g_scratchPtr[c->device];  // never the array's name: that is a host-side stand-in
+    hipStream_t st   = stream ? (hipStream_t)stream : c->stream;
+    BvhView     bvh;
+    fill_bvh_view(c, bvh);
+    // the array keeps the last call's cursor: it must start at zero
+    HIPCHK(c, hipMemsetAsync(work, 0, PRT_NOALLOC_SCRATCH_BYTES, st));
+    if(any)
+        hipLaunchKernelGGL(k_trace_batch<true>, dim3(c->gridBatch), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
+                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune());
+    else
+        hipLaunchKernelGGL(k_trace_batch<false>, dim3(c->gridBatch), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
+                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune());
+    HIPCHK(c, hipGetLastError());
     return PRT_OK;
 }
 
