@@ -27,6 +27,8 @@ static std::string esc(const std::string& s)
     std::string o;
     for(char c : s)
     {
+        if(c == '\n') { o += "\\n"; continue; }
+        if(c == '\t') { o += "\\t"; continue; }
         if(c == '\\' || c == '"') o += '\\';
         o += c;
     }
@@ -41,8 +43,68 @@ static void mat(FILE* f, const char* name, const glm::mat4& m, bool comma = true
     fprintf(f, "]%s\n", comma ? "," : "");
 }
 
+// tinyobj::LoadObj as Model.cpp:54 calls it (triangulate = true, default_vcols_fallback = true), dumped as one JSON object
+static void dump_obj(FILE* f, const char* objPath, const char* mtlDir)
+{
+    tinyobj::attrib_t                attrib;
+    std::vector<tinyobj::shape_t>    shapes;
+    std::vector<tinyobj::material_t> materials;
+    std::string                      warn, err;
+    bool ok = tinyobj::LoadObj(&attrib, &shapes, &materials, &warn, &err, objPath, mtlDir);
+    fprintf(f, "\"obj\": {\"ok\": %s,\n", ok ? "true" : "false");
+    auto farr = [&](const char* n, const std::vector<float>& v) {
+        fprintf(f, "\"%s\": [", n);
+        for(size_t i = 0; i < v.size(); ++i) fprintf(f, "%.9g%s", v[i], i + 1 < v.size() ? ", " : "");
+        fprintf(f, "],\n");
+    };
+    farr("vertices", attrib.vertices);
+    farr("normals", attrib.normals);
+    farr("texcoords", attrib.texcoords);
+    farr("colors", attrib.colors);
+    fprintf(f, "\"shapes\": [\n");
+    for(size_t s = 0; s < shapes.size(); ++s)
+    {
+        fprintf(f, "{\"name\": \"%s\", \"indices\": [", esc(shapes[s].name).c_str());
+        const auto& ix = shapes[s].mesh.indices;
+        for(size_t i = 0; i < ix.size(); ++i)
+            fprintf(f, "[%d, %d, %d]%s", ix[i].vertex_index, ix[i].normal_index, ix[i].texcoord_index,
+                    i + 1 < ix.size() ? ", " : "");
+        fprintf(f, "], \"material_ids\": [");
+        const auto& mi = shapes[s].mesh.material_ids;
+        for(size_t i = 0; i < mi.size(); ++i) fprintf(f, "%d%s", mi[i], i + 1 < mi.size() ? ", " : "");
+        fprintf(f, "]}%s\n", s + 1 < shapes.size() ? "," : "");
+    }
+    fprintf(f, "],\n\"materials\": [\n");
+    for(size_t m = 0; m < materials.size(); ++m)
+    {
+        const auto& t = materials[m];
+        fprintf(f, "{\"name\": \"%s\", \"ambient\": [%.9g, %.9g, %.9g], \"diffuse\": [%.9g, %.9g, %.9g], "
+                   "\"specular\": [%.9g, %.9g, %.9g], \"transmittance\": [%.9g, %.9g, %.9g], "
+                   "\"emission\": [%.9g, %.9g, %.9g], \"shininess\": %.9g, \"ior\": %.9g, \"dissolve\": %.9g, "
+                   "\"illum\": %d, \"roughness\": %.9g, \"metallic\": %.9g, \"diffuse_texname\": \"%s\", "
+                   "\"specular_texname\": \"%s\", \"bump_texname\": \"%s\"}%s\n",
+                esc(t.name).c_str(), t.ambient[0], t.ambient[1], t.ambient[2], t.diffuse[0], t.diffuse[1], t.diffuse[2],
+                t.specular[0], t.specular[1], t.specular[2], t.transmittance[0], t.transmittance[1],
+                t.transmittance[2], t.emission[0], t.emission[1], t.emission[2], t.shininess, t.ior, t.dissolve,
+                t.illum, t.roughness, t.metallic,
+                esc(t.diffuse_texname).c_str(), esc(t.specular_texname).c_str(), esc(t.bump_texname).c_str(), m + 1 < materials.size() ? "," : "");
+    }
+    fprintf(f, "], \"warn\": \"%s\", \"err\": \"%s\"}", esc(warn).c_str(), esc(err).c_str());
+}
+
 int main(int argc, char** argv)
 {
+    // ref_host_dump --obj <obj> <mtl dir> <out.json>: the loader's output for one more OBJ file (tests/golden/obj_cases)
+    if(argc == 5 && std::string(argv[1]) == "--obj")
+    {
+        FILE* f = fopen(argv[4], "w");
+        if(!f) return 1;
+        fprintf(f, "{");
+        dump_obj(f, argv[2], argv[3]);
+        fprintf(f, "}\n");
+        fclose(f);
+        return 0;
+    }
     if(argc < 4) return 2;
     FILE* f = fopen(argv[3], "w");
     if(!f) return 1;
@@ -84,50 +146,8 @@ int main(int argc, char** argv)
     }
     fprintf(f, "],\n");
 
-    tinyobj::attrib_t                attrib;
-    std::vector<tinyobj::shape_t>    shapes;
-    std::vector<tinyobj::material_t> materials;
-    std::string                      warn, err;
-    bool ok = tinyobj::LoadObj(&attrib, &shapes, &materials, &warn, &err, argv[1], argv[2]);
-    fprintf(f, "\"obj\": {\"ok\": %s,\n", ok ? "true" : "false");
-    auto farr = [&](const char* n, const std::vector<float>& v) {
-        fprintf(f, "\"%s\": [", n);
-        for(size_t i = 0; i < v.size(); ++i) fprintf(f, "%.9g%s", v[i], i + 1 < v.size() ? ", " : "");
-        fprintf(f, "],\n");
-    };
-    farr("vertices", attrib.vertices);
-    farr("normals", attrib.normals);
-    farr("texcoords", attrib.texcoords);
-    farr("colors", attrib.colors);
-    fprintf(f, "\"shapes\": [\n");
-    for(size_t s = 0; s < shapes.size(); ++s)
-    {
-        fprintf(f, "{\"name\": \"%s\", \"indices\": [", shapes[s].name.c_str());
-        const auto& ix = shapes[s].mesh.indices;
-        for(size_t i = 0; i < ix.size(); ++i)
-            fprintf(f, "[%d, %d, %d]%s", ix[i].vertex_index, ix[i].normal_index, ix[i].texcoord_index,
-                    i + 1 < ix.size() ? ", " : "");
-        fprintf(f, "], \"material_ids\": [");
-        const auto& mi = shapes[s].mesh.material_ids;
-        for(size_t i = 0; i < mi.size(); ++i) fprintf(f, "%d%s", mi[i], i + 1 < mi.size() ? ", " : "");
-        fprintf(f, "]}%s\n", s + 1 < shapes.size() ? "," : "");
-    }
-    fprintf(f, "],\n\"materials\": [\n");
-    for(size_t m = 0; m < materials.size(); ++m)
-    {
-        const auto& t = materials[m];
-        fprintf(f, "{\"name\": \"%s\", \"ambient\": [%.9g, %.9g, %.9g], \"diffuse\": [%.9g, %.9g, %.9g], "
-                   "\"specular\": [%.9g, %.9g, %.9g], \"transmittance\": [%.9g, %.9g, %.9g], "
-                   "\"emission\": [%.9g, %.9g, %.9g], \"shininess\": %.9g, \"ior\": %.9g, \"dissolve\": %.9g, "
-                   "\"illum\": %d, \"roughness\": %.9g, \"metallic\": %.9g, \"diffuse_texname\": \"%s\", "
-                   "\"specular_texname\": \"%s\", \"bump_texname\": \"%s\"}%s\n",
-                t.name.c_str(), t.ambient[0], t.ambient[1], t.ambient[2], t.diffuse[0], t.diffuse[1], t.diffuse[2],
-                t.specular[0], t.specular[1], t.specular[2], t.transmittance[0], t.transmittance[1],
-                t.transmittance[2], t.emission[0], t.emission[1], t.emission[2], t.shininess, t.ior, t.dissolve,
-                t.illum, t.roughness, t.metallic,
-                esc(t.diffuse_texname).c_str(), esc(t.specular_texname).c_str(), esc(t.bump_texname).c_str(), m + 1 < materials.size() ? "," : "");
-    }
-    fprintf(f, "]},\n\"textures\": {\n");
+    dump_obj(f, argv[1], argv[2]);
+    fprintf(f, ",\n\"textures\": {\n");
     for(int i = 4; i < argc; ++i)
     {
         int      w = 0, h = 0, c = 0;

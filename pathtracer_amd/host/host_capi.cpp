@@ -89,6 +89,8 @@ static std::string jesc(const std::string& s)
     std::string o;
     for(char c : s)
     {
+        if(c == '\n') { o += "\\n"; continue; }
+        if(c == '\t') { o += "\\t"; continue; }
         if(c == '\\' || c == '"') o += '\\';
         o += c;
     }
@@ -139,7 +141,7 @@ int prth_obj_dump_json(const char* objPath, const char* mtlDir, const char* json
                 jesc(t.diffuse_texname).c_str(), jesc(t.specular_texname).c_str(), jesc(t.bump_texname).c_str(),
                 m + 1 < d.materials.size() ? "," : "");
     }
-    fprintf(f, "], \"warn\": \"%s\"}\n", jesc(d.warn).c_str());
+    fprintf(f, "], \"warn\": \"%s\", \"err\": \"%s\"}\n", jesc(d.warn).c_str(), jesc(err).c_str());
     fclose(f);
     return ok ? 0 : -2;
 }

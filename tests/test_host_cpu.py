@@ -50,17 +50,13 @@ def test_camera_and_uniform_block_bit_exact(golden):
     assert ubo["lightSourceArea"] == np.float32(0.3) and ubo["samplesPerPixel"] == 128
 
 
-def test_obj_reader_equals_the_reference_loader(golden, tmp_path):
-    out = tmp_path / "mine.json"
-    rc = hostapi.lib().prth_obj_dump_json(os.path.join(G, "obj", "mixed.obj").encode(), (os.path.join(G, "obj") + "/").encode(),
-                                          str(out).encode())
-    assert rc == 0
-    mine, ref = json.load(open(out), parse_int=float), golden["obj"]
+def _same_obj(mine, ref):
+    assert mine["ok"] == ref["ok"]
     for k in ("vertices", "normals", "texcoords", "colors"):
         assert f32(mine[k]).tobytes() == f32(ref[k]).tobytes(), k
     assert [s["name"] for s in mine["shapes"]] == [s["name"] for s in ref["shapes"]]
     for a, b in zip(mine["shapes"], ref["shapes"]):
-        assert a["indices"] == b["indices"] and a["material_ids"] == b["material_ids"]
+        assert a["indices"] == b["indices"] and a["material_ids"] == b["material_ids"], a["name"]
     assert len(mine["materials"]) == len(ref["materials"])
     for a, b in zip(mine["materials"], ref["materials"]):
         for k, v in b.items():
@@ -68,6 +64,61 @@ def test_obj_reader_equals_the_reference_loader(golden, tmp_path):
                 assert a[k] == v, (b["name"], k)
             else:
                 assert f32(a[k]).tobytes() == f32(v).tobytes(), (b["name"], k)
+    if "warn" in ref:  # the messages too (they carry line numbers)
+        assert mine["warn"] == ref["warn"] and mine["err"] == ref["err"]
+
+
+def test_obj_reader_equals_the_reference_loader(golden, tmp_path):
+    out = tmp_path / "mine.json"
+    rc = hostapi.lib().prth_obj_dump_json(os.path.join(G, "obj", "mixed.obj").encode(), (os.path.join(G, "obj") + "/").encode(),
+                                          str(out).encode())
+    assert rc == 0
+    _same_obj(json.load(open(out), parse_int=float), golden["obj"])
+
+
+# tests/golden/obj_cases/*.json = tinyobj::LoadObj output (oracle/ref_host_dump --obj) for hand-written files:
+#   ngons    concave / clockwise / star-shaped / collinear-start / non-planar / degenerate / bow-tie polygons in all
+#            three projection planes, faces with 1 and 2 corners
+#   indices  negative (relative) indices, i/t and i//n forms, out-of-range indices, vertex colours (full, partial),
+#            number forms (exponents, ".5", "1e", "+3", "-0.0", long fractions), first mtllib name missing, a material
+#            before any newmtl, `d` before / after `Tr`, unknown usemtl names (with a trailing blank), repeated usemtl
+#   groups   flush order of o / g / usemtl, `g` with several / no names, bare keywords, lines and points keeping a
+#            shape alive, a trailing usemtl
+#   textures texture-statement options (with too few arguments, at the end of a line), names with blanks and
+#            backslashes, map_d, later statements overriding earlier ones
+#   crlf     \r\n and lone \r line ends, no newline at the end
+@pytest.mark.parametrize("case", ["ngons", "indices", "groups", "textures", "crlf"])
+def test_obj_reader_cases_equal_the_reference_loader(case, tmp_path):
+    d = os.path.join(G, "obj_cases")
+    # the goldens were made with the paths below relative to the repository root (they appear in warnings)
+    out = tmp_path / "mine.json"
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        hostapi.lib().prth_obj_dump_json(f"tests/golden/obj_cases/{case}.obj".encode(), b"tests/golden/obj_cases/", str(out).encode())
+    finally:
+        os.chdir(cwd)
+    ref = json.load(open(os.path.join(d, case + ".json")), parse_int=float)["obj"]
+    mine = json.load(open(out), parse_int=float)
+    assert len(ref["shapes"]) > 0
+    _same_obj(mine, ref)
+
+
+def test_obj_reader_rejects_what_the_reference_loader_rejects(tmp_path):
+    # (verified with oracle/_ref/ref_host_dump; 16 000 random files: oracle/fuzz_obj_vs_ref.py, no difference)
+    for text in ("v 0 0 0\nf 1 0 1\n", "v 0 0 0\nf 1/1/1/1 1 1\n", "v 0 0 0\nl 1 x\n", "v 0 0 0\np 0\n",
+                 "v 0 0 0\nf 1 1 1 # c\n", "v 0 0 0\nf 1/ \n"):
+        p = tmp_path / "bad.obj"
+        p.write_text(text)
+        with pytest.raises(hostapi.HostError):
+            hostapi.load_model(str(p))
+    # ... and accepts what it accepts: a corner ending in '/' takes the number from the next word (atoi skips blanks)
+    p = tmp_path / "odd.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0.25 0.5\nvn 0 0 1\nf 1/ 1 2 3\nf 1//  1 2 3\n")
+    out = tmp_path / "odd.json"
+    assert hostapi.lib().prth_obj_dump_json(str(p).encode(), b"", str(out).encode()) == 0
+    sh = json.load(open(out))["shapes"][0]["indices"]
+    assert sh[:3] == [[0, -1, 0], [0, -1, -1], [1, -1, -1]] and sh[6:9] == [[0, 0, -1], [0, -1, -1], [1, -1, -1]]
 
 
 def _expected_model(ref):
