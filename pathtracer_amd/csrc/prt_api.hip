@@ -529,10 +529,11 @@ static int emit_layout(prt_context* c)
     dfree(c->dNodes);
     dfree(c->dTris);
     BCHK(dalloc(c->dNodes, (size_t)(nInner ? nInner : 1) * 4));
-    BCHK(dalloc(c->dTris, (size_t)3 * N));
+    BCHK(dalloc(c->dTris, (size_t)PRT_LEAF_SLOT_F4 * N));
     hipLaunchKernelGGL(k_emit_wide, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, c->lt, flags,
                        c->grid, c->dNodes);
-    hipLaunchKernelGGL(k_emit_tris, dim3(cdiv(N, 256)), dim3(256), 0, st, c->dVerts, c->dIdx, c->dOrder, N, c->dTris);
+    hipLaunchKernelGGL(k_emit_leaves, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, c->dVerts, c->dIdx,
+                       c->dOrder, c->dTris);
     BCHK(hipGetLastError());
     BCHK(hipStreamSynchronize(st));
     cleanup();

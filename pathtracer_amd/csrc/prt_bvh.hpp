@@ -3,7 +3,7 @@
 // external/NVIDIA_RTX/vkRT_BLAS.cpp:271). One instance, identity transform, opaque, two-sided:
 // a single-level BVH over the triangles of model 0.
 //
-// Algorithm: breadth-first, one pass of kernels per tree level, 16 bins per axis, leaves <= 4
+// Algorithm: breadth-first, one pass of kernels per tree level, 16 bins per axis, leaves <= PRT_LEAF_MAX (2)
 // triangles. Everything that decides the tree is order-independent: bin counts are integer
 // atomics, bin / node / centroid bounds are integer atomicMin/Max on order-preserving float keys,
 // SAH costs are evaluated per node in a fixed order, child slots and the stable partition come
@@ -682,20 +682,32 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
                           qmx[k][2] | (qmx[k][3] << 16));
     o[3] = make_uint4((uint32_t)ref[0], (uint32_t)ref[1], (uint32_t)ref[2], (uint32_t)ref[3]);
 }
-__global__ void __launch_bounds__(256) k_emit_tris(const prt_vertex* __restrict__ verts,
-                                                   const uint32_t* __restrict__ idx,
-                                                   const uint32_t* __restrict__ order, uint32_t ntri,
-                                                   float4* __restrict__ tris)
+// Leaf records. A leaf over order[first .. first+count) keeps its triangles (3 x float4 each, prim id in v0.w) in the
+// 128-byte slots first .. first+count-1 of the triangle array, packed from the start of slot `first`: a leaf of <= 2
+// triangles is ONE aligned 128-byte line. Measured (tools/ubench_gather.hip): what a divergent gather costs a CU is the
+// number of 128-byte lines it touches, and triangle records packed at 48-byte pitch straddle a line boundary in
+// 25 % (one triangle) / 62 % (two) of the leaves. The slots that follow `first` inside a leaf stay unused (never read).
+#define PRT_LEAF_SLOT_F4 8  // float4 per slot
+__global__ void __launch_bounds__(256) k_emit_leaves(const BuildNode* __restrict__ nodes, uint32_t nnodes,
+                                                     const prt_vertex* __restrict__ verts,
+                                                     const uint32_t* __restrict__ idx,
+                                                     const uint32_t* __restrict__ order, float4* __restrict__ tris)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if(i >= ntri) return;
-    const uint32_t p  = order[i];
-    const float*   a  = verts[idx[3 * p]].p;
-    const float*   b  = verts[idx[3 * p + 1]].p;
-    const float*   c  = verts[idx[3 * p + 2]].p;
-    tris[3 * i]       = make_float4(a[0], a[1], a[2], __int_as_float((int)p));
-    tris[3 * i + 1]   = make_float4(b[0], b[1], b[2], 0.0f);
-    tris[3 * i + 2]   = make_float4(c[0], c[1], c[2], 0.0f);
+    if(i >= nnodes) return;
+    const uint32_t first = nodes[i].first, count = nodes[i].count;
+    if(count == 0) return;
+    float4* o = tris + (size_t)first * PRT_LEAF_SLOT_F4;
+    for(uint32_t q = 0; q < count; ++q)
+    {
+        const uint32_t p = order[first + q];
+        const float*   a = verts[idx[3 * p]].p;
+        const float*   b = verts[idx[3 * p + 1]].p;
+        const float*   c = verts[idx[3 * p + 2]].p;
+        o[3 * q]         = make_float4(a[0], a[1], a[2], __int_as_float((int)p));
+        o[3 * q + 1]     = make_float4(b[0], b[1], b[2], 0.0f);
+        o[3 * q + 2]     = make_float4(c[0], c[1], c[2], 0.0f);
+    }
 }
 // float view of the build nodes for prt_read_bvh()
 __global__ void __launch_bounds__(256) k_decode_nodes(const BuildNode* __restrict__ nodes, uint32_t nnodes,

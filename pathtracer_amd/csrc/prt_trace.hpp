@@ -6,8 +6,9 @@
 //   row of four child references. The traversal kernels are bound by the vector-memory pipeline
 //   (TA/TCP: random 16-byte requests), not by VALU or HBM, so bytes and loads per visit are what counts;
 //   the de-quantisation folds into the per-ray slab constants: t = fma(float(q), r*scale, c').
-// * Leaves reference runs of <= 4 pre-gathered triangles, 48 bytes each (3 x float4, prim id in
-//   v0.w), laid out in leaf order so a leaf is one contiguous 48..192-byte read.
+// * Leaves reference runs of <= 2 pre-gathered triangles, 48 bytes each (3 x float4, prim id in
+//   v0.w), packed into ONE aligned 128-byte record per leaf (what a divergent gather costs is the number of
+//   128-byte lines it touches: tools/ubench_gather.hip).
 // * Per-lane traversal stack: the first PRT_LDS_STACK entries live in LDS, laid out [entry][lane] so
 //   that a wave's push/pop is one conflict-free ds_write_b32/ds_read_b32; deeper entries (rare)
 //   spill to scratch.
@@ -54,7 +55,7 @@ constexpr int32_t kEmptyLeaf = -1;          // ~0: leaf reference with count 0
 struct BvhView
 {
     const uint4*  nodes;  // 4 x uint4 per BVH4 node
-    const float4* tris;   // 3 x float4 per triangle, leaf order
+    const float4* tris;   // one 128-byte slot per triangle position; a leaf's triangles are packed into its first slot(s)
     int32_t       root;   // node index (0), or a leaf reference when the scene has <= 4 triangles
     float         sceneAbs;
     float         qmin[3], qscale[3];  // box coordinate = qmin + q * qscale, q in [0, 65535]
@@ -317,7 +318,7 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
     const uint32_t ref   = ~(uint32_t)leafRef;
     const uint32_t first = ref >> 3, count = ref & 7u;
     if(count == 0) return false;
-    const float4* t = bvh.tris + (size_t)first * 3;
+    const float4* t = bvh.tris + (size_t)first * 8;  // the leaf's 128-byte slot (k_emit_leaves)
 #if PRT_TRI_PREFETCH
     float4        a = t[0], b = t[1], c = t[2];
 #endif
