@@ -10,10 +10,13 @@ scene is replicated, rank r renders iterations r+1, r+1+N, ... (sample sharding,
 float4 buffer and the buffers are summed with one RCCL all-reduce inside the timed region ("weak" scaling:
 K iterations per GPU whatever N is). Inputs (scene, BVH, uniforms) are resident in HBM before timing starts.
 
-One JSON line on stdout (rank 0). `roofline` is for the dominant kernel (closest-hit or any-hit traversal):
-algorithmic bytes per ray x rays per launch / mean launch duration from HIP events recorded on the
-library's stream during the timed region. `cpu_baseline` is the CPU oracle (oracle/, a port of the reference
-shaders — the reference has no CPU path) timed on this host on a bounded sample of the same workload.
+One JSON line on stdout (rank 0). `roofline` is for the dominant kernel (the fused traversal launch): HBM-side bytes
+per launch (PMC FETCH_SIZE / WRITE_SIZE of the committed rocprofv3 passes, per ray, scaled to this run) / the kernel's
+own duration (HIP events on the library's stream, one pass in flight, measured in this run after the timed region) /
+8 TB/s; `roofline.binding` says what actually bounds the kernel, `roofline.algorithmic` is the SURVEY 8(d) byte
+formula on the same duration, `roofline.in_pipeline` the launch duration inside the timed region. `cpu_baseline` is
+the CPU oracle (oracle/, a port of the reference shaders — the reference has no CPU path) on all CPUs this process may
+use, on a bounded sample of the same workload.
 """
 from __future__ import annotations
 
@@ -40,6 +43,33 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def host_cpus():
+    """What this process may use of the host: logical CPUs of the machine, CPUs in its affinity mask, cgroup CPU quota."""
+    info = {"cpu_count": os.cpu_count()}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        info["affinity"] = None
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    info["cgroup_quota"] = quota
+    return info
+
+
+def host_threads():
+    """Threads of the CPU baseline: every CPU this process is allowed to run on."""
+    h = host_cpus()
+    n = h["affinity"] or h["cpu_count"] or 1
+    if h["cgroup_quota"]:
+        n = min(n, max(1, int(h["cgroup_quota"] + 0.5)))
+    return max(1, n)
 
 
 def main():
@@ -165,7 +195,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_rays = float(rays.item())
     elapsed = float(tmax.item())
-    finite = bool(torch.isfinite(accum[..., 3]).all().item())
+    finite = bool(torch.isfinite(accum).all().item())  # all four channels
 
     roofline = None
     kernels = {}
@@ -202,37 +232,15 @@ def main():
             nn, nt = (cn, ct) if kind == capi.K_EXTEND else (an, at)
         launches = max(1, int(p.launches[kind]))
         ms_launch = p.ms[kind] / launches
-        bytes_launch = b_ray * nrays / launches
-        achieved = bytes_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                t = json.load(open(pmc)).get(kname.split(" ")[0], {})
-                traffic = t.get("hbm_bytes_per_launch")
-                if t.get("hbm_bytes_per_ray"):  # counters were taken at another launch size: scale to this run's
-                    traffic = int(t["hbm_bytes_per_ray"] * nrays / launches)
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(nn, 2), "tris_per_ray": round(nt, 2),
-                    "rays_per_launch": round(nrays / launches, 1), "ms_per_launch": round(ms_launch, 4),
-                    "launches": launches,
-                    "traffic_rate": None if not traffic else {
-                        "GB/s": round(traffic / (ms_launch * 1e-3) / 1e9, 1),
-                        "frac_of_peak": round(traffic / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "what": "bytes that left L2 per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json; "
-                                "Infinity-Cache hits included) / this run's launch time: the scene's BVH lives in "
-                                "L2 / Infinity Cache, so the algorithmic rate above can exceed the HBM peak"},
-                    "note": "ms_per_launch is wall time of a launch on its own stream while the other in-flight "
-                            "iterations' kernels share the GPU (pipelined passes), so it understates the kernel's "
-                            "stand-alone rate",
-                    "other": {"closest": {"nodes_per_ray": round(cn, 2), "tris_per_ray": round(ct, 2)},
-                              "any": {"nodes_per_ray": round(an, 2), "tris_per_ray": round(at, 2)}}}
+        rays_launch = nrays / launches
+        alg_rate = b_ray * rays_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
+        in_pipeline = {"ms_per_launch": round(ms_launch, 4), "launches": launches, "rays_per_launch": round(rays_launch, 1),
+                       "algorithmic_GB/s": round(alg_rate, 1),
+                       "what": "HIP events on the launch's own stream over the timed region; with several passes in flight the "
+                               "launch shares the GPU with the other streams' kernels, so this is not the kernel's own duration"}
 
     # the dominant kernel on its own: same workload with one iteration in flight (untimed extra, after `value`)
-    if roofline is not None:
+    if not args.no_profile:
         ctx.set_pipeline_depth(1)
         ctx.set_profiling_mask(0xffffffff)
         ctx.reset_stats()
@@ -246,10 +254,55 @@ def main():
         ms1 = p1.ms[kind] / l1
         r1, by1 = kind_work(p1, kind)
         n1 = r1 / l1
-        a1 = by1 / l1 / (ms1 * 1e-3) / 1e9 if ms1 > 0 else 0.0
-        roofline["standalone"] = {"ms_per_launch": round(ms1, 4), "achieved": round(a1, 2),
-                                  "frac": round(a1 / HBM_PEAK_GBS, 5), "rays_per_launch": round(n1, 1),
-                                  "what": "same kernel with pipeline depth 1 (no other kernel sharing the GPU)"}
+        alg1 = by1 / l1 / (ms1 * 1e-3) / 1e9 if ms1 > 0 else 0.0
+        # HBM-side traffic of the kernel: PMC counters cannot be read inside this process; they come from the committed
+        # rocprofv3 passes over this same command (tools/profile.sh -> profiles/pmc_traffic.json), per ray, scaled to
+        # this run's rays per launch
+        traffic = src = None
+        binding = {}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                allk = json.load(open(pmc))
+                t = allk.get(kname.split(" ")[0], {})
+                if t.get("hbm_bytes_per_ray"):
+                    traffic = int(t["hbm_bytes_per_ray"] * n1)
+                    src = (f"profiles/pmc_traffic.json [{allk.get('_tag', '?')}]: (FETCH_SIZE x {t.get('fetch_correction', 2)} + WRITE_SIZE) "
+                           f"per ray = {t['hbm_bytes_per_ray']} B at {t.get('rays_per_launch')} rays per launch, scaled to this run's "
+                           f"{n1:.0f} rays per launch; counted at the L2's fabric side, so Infinity-Cache hits are included "
+                           f"(upper bound on HBM bytes)")
+                for key in ("l2_hit_rate", "valu_busy_simd", "valu_active_per_wave_cycle", "wait_any_per_wave_cycle",
+                            "tcp_tcc_read_req_per_ray", "l1_miss_lines_per_clk_per_cu", "l1_miss_ceiling_lines_per_clk_per_cu"):
+                    if key in t:
+                        binding[key] = t[key]
+            except Exception:
+                traffic = src = None
+        st2 = prof2.closest_steps if kind == capi.K_EXTEND else prof2.any_steps if kind == capi.K_SHADOW else None
+        def lanes(sx):
+            return {"node_steps": round(sx.node_lanes / max(1, 64 * sx.node_steps), 3),
+                    "triangle_steps": round(sx.tri_lanes / max(1, 64 * sx.tri_steps), 3),
+                    "ray_setup": round(sx.setup_lanes / max(1, 64 * sx.setup_steps), 3)}
+        binding["lane_utilisation"] = ({"closest": lanes(prof2.closest_steps), "any": lanes(prof2.any_steps)}
+                                       if st2 is None else lanes(st2))
+        binding["what"] = ("not HBM: the kernel is bound by the latency of dependent, divergent 16-byte gathers (one L2 / "
+                           "Infinity-Cache round trip per node visit, the wave waits for its slowest lane) at the 6 waves per "
+                           "SIMD its registers allow; DESIGN.md section 5")
+        achieved = traffic / (ms1 * 1e-3) / 1e9 if traffic and ms1 > 0 else None
+        roofline = {"bound": "hbm", "kernel": kname,
+                    "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_source": src,
+                    "ms_per_launch": round(ms1, 4), "rays_per_launch": round(n1, 1),
+                    "what": "HBM-side bytes of one launch / the kernel's own duration (HIP events, one pass in flight, "
+                            "measured in this run) / 8 TB/s",
+                    "binding": binding,
+                    "algorithmic": {"bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(nn, 2), "tris_per_ray": round(nt, 2),
+                                    "GB/s": round(alg1, 1), "frac_of_hbm_peak": round(alg1 / HBM_PEAK_GBS, 4),
+                                    "what": "SURVEY.md 8(d) bytes per ray x rays / the same duration: every node visit counted as "
+                                            "64 B although L2 / Infinity Cache serve the re-reads, so this may exceed the HBM peak",
+                                    "closest": {"nodes_per_ray": round(cn, 2), "tris_per_ray": round(ct, 2)},
+                                    "any": {"nodes_per_ray": round(an, 2), "tris_per_ray": round(at, 2)}},
+                    "in_pipeline": in_pipeline}
         accum.zero_()
 
     cpu_baseline = None
@@ -257,7 +310,7 @@ def main():
         try:
             from oracle import pyoracle as po
 
-            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            threads = args.cpu_threads or host_threads()
             orc = po.Oracle(scene, seed=2)
             orc.build_bvh()
             t1 = time.perf_counter()
@@ -269,15 +322,16 @@ def main():
                 crays += r
             dt = time.perf_counter() - t1
             cpu_baseline = {"value": round(crays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                            "sample": f"{cit} iterations (1 spp each, {crays} rays) of the same {W}x{H} conference "
-                                      f"workload, {dt:.1f} s, oracle/liboracle.so"}
+                            "sample": f"{cit} iterations (1 spp each, {crays} rays) of the same {W}x{H} {args.scene} "
+                                      f"workload, {dt:.1f} s, oracle/liboracle.so on {threads} threads",
+                            "host": host_cpus()}
         except Exception as e:  # the baseline is a report, never a dependency of the GPU path
             cpu_baseline = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
     if rank == 0:
         value = total_rays / elapsed / 1e6
         out = {
-            "metric": "Mrays/s (whole node, incl. secondary) conference 1080p",
+            "metric": f"Mrays/s (whole node, incl. secondary) {args.scene} {'1080p' if (W, H) == (1920, 1080) else f'{W}x{H}'}",
             "value": round(value, 2),
             "unit": "Mrays/s",
             "n_gpus": n_gpus,

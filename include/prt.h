@@ -71,7 +71,8 @@ typedef struct prt_stats
     uint32_t bvh_depth;
     float    bvh_build_ms;    /* wall time of the last prt_build_accel */
     float    bvh_refit_ms;    /* wall time of the last prt_refit_accel */
-    uint32_t pad_;
+    uint32_t trace_overruns;  /* traversal waves that hit their safety bound and dropped rays: 0 unless the
+                                 acceleration structure in device memory was corrupted */
 } prt_stats;
 
 /* Kernel kinds of prt_profile */

@@ -87,6 +87,31 @@ int prth_render_model(const prth_model* model, int device, uint32_t width, uint3
                       uint32_t first_iteration, uint32_t n_iterations, const char* resume_from, const char* save_to,
                       float* accum_out, char* err, size_t err_len);
 
+/* vkContext::mainLoop / renderFrame (vkContext.cpp:92-231) without the window: n_frames calls of
+ * Renderer::renderFrame with the reference's image semantics (PRT_FLAG_LITERAL), each preceded by the input events
+ * scheduled for that frame. records[f] receives the parameter block of frame f (what vkContext memcpy's into the UBO,
+ * vkContext.cpp:1057-1059), the progressive counter m_settings.iteration before and after updateGraphicsUniforms, and
+ * whether the frame traced rays (vkContext.cpp:164: only while iteration < samplesPerPixel). Needs a GPU. */
+#define PRTH_EVENT_MOVE_CAMERA 0 /* v = movement input (right, up, forward) for one second: CameraControls::updateMovements */
+#define PRTH_EVENT_MOVE_LIGHT 1  /* the Space key: m_moveLight = true (the light jumps to the camera one frame later) */
+#define PRTH_EVENT_SET_MODE 2    /* v[0] = 0: path tracing, 1: ambient occlusion (KP1 / KP2) */
+typedef struct prth_frame_event
+{
+    uint32_t frame;
+    int32_t  kind;
+    float    v[3];
+} prth_frame_event;
+typedef struct prth_frame_record
+{
+    prt_uniforms ubo;
+    uint32_t     settings_iteration_before, settings_iteration_after;
+    int32_t      traced;
+    uint32_t     pad_;
+} prth_frame_record;
+int prth_frame_loop(const prth_model* model, int device, uint32_t width, uint32_t height, const prth_settings* settings,
+                    const float eye[3], const float target[3], const prth_frame_event* events, size_t n_events,
+                    uint32_t n_frames, prth_frame_record* records, float* accum_out, char* err, size_t err_len);
+
 /* Image and state files of the headless renderer (the reference only presents to a swapchain). */
 int prth_write_png(const char* path, const uint8_t* rgba, uint32_t width, uint32_t height);
 int prth_checkpoint_write(const char* path, uint32_t width, uint32_t height, uint32_t next_iteration, int32_t mode,

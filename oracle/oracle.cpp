@@ -778,11 +778,14 @@ inline vec3 textureRGB(const Tex& t, vec2 uv)
     auto wrap = [](float f, uint32_t n) -> uint32_t {
         // f is integral; bring into [0,n)
         float m = f - floorf(f / (float)n) * (float)n;
-        int   i = (int)m;
+        if(!(m == m)) return 0u;  // NaN coordinate: texel 0
+        int i = (int)m;
         if(i < 0)
             i += (int)n;
         if(i >= (int)n)
             i -= (int)n;
+        if(i < 0) i = 0;  // |f| beyond 2^24 * n
+        if(i >= (int)n) i = (int)n - 1;
         return (uint32_t)i;
     };
     const uint32_t x0 = wrap(x0f, t.w), x1 = wrap(x0f + 1.0f, t.w);
@@ -1499,7 +1502,43 @@ uint64_t orc_render(const orc_scene* sc, const prt_uniforms* ubo, uint32_t w, ui
     return total.load();
 }
 
-// pathRTpostprocess.comp:38-51. pow(c, 1/2.2) via powf — display-side, not part of the parity contract.
+// pow(x, 1/2.2) of the post-process (pathRTpostprocess.comp:48). GLSL leaves the rounding of pow open; this is the
+// definition the build uses, the same expression tree in the oracle and in the kernel, so the RGBA8 image is bit-exact:
+// x = m 2^e with m in [sqrt(1/2), sqrt(2)), log2 m by the atanh series in s = (m-1)/(m+1) up to s^9, y = log2(x) / 2.2,
+// 2^y = 2^n exp(f ln 2) with the Taylor polynomial of degree 7 on |f| <= 1/2 (relative error < 3e-7).
+// x <= 0 or NaN gives 0 (the UNORM store would clamp them to 0 anyway).
+static inline int float_bits(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline float bits_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+float orc_gamma(float x)
+{
+    if(!(x > 0.0f)) return 0.0f;
+    if(x > 3.0e38f) return x;
+    float scale_e = 0.0f;
+    if(x < 1.17549435e-38f)
+    {
+        x       = x * 16777216.0f;
+        scale_e = -24.0f;
+    }
+    const int ix = float_bits(x);
+    int       e  = ((ix >> 23) & 0xff) - 127;
+    float     m  = bits_float((ix & 0x007fffff) | 0x3f800000);
+    if(m > 1.41421356f)
+    {
+        m = m * 0.5f;
+        e = e + 1;
+    }
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float z = s * s;
+    const float p = ((((z * 0.111111111f + 0.142857143f) * z + 0.2f) * z + 0.333333333f) * z) + 1.0f;
+    const float l = ((float)e + scale_e) + (2.88539008f * s) * p;
+    const float y = l * 0.454545455f;
+    const float n = floorf(y + 0.5f);
+    const float t = (y - n) * 0.693147181f;
+    const float q = ((((((t * 1.98412698e-4f + 1.38888889e-3f) * t + 8.33333333e-3f) * t + 4.16666667e-2f) * t + 0.166666667f) * t + 0.5f) * t + 1.0f) * t + 1.0f;
+    return bits_float(float_bits(q) + ((int)n << 23));
+}
+
+// pathRTpostprocess.comp:38-51
 void orc_postprocess(const float* accum, uint32_t w, uint32_t h, uint8_t* out)
 {
     for(size_t i = 0; i < (size_t)w * h; ++i)
@@ -1509,7 +1548,7 @@ void orc_postprocess(const float* accum, uint32_t w, uint32_t h, uint8_t* out)
             for(int k = 0; k < 4; ++k)
                 c[k] /= c[3];
         for(int k = 0; k < 3; ++k)
-            c[k] = powf(c[k], 1.0f / 2.2f);
+            c[k] = orc_gamma(c[k]);
         for(int k = 0; k < 4; ++k)
         {
             float v = c[k];

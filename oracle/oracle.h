@@ -92,6 +92,7 @@ uint64_t orc_render(const orc_scene*, const prt_uniforms* ubo, uint32_t w, uint3
 
 /* pathRTpostprocess.comp:38-51 over the full image. out = RGBA8. */
 void orc_postprocess(const float* accum, uint32_t w, uint32_t h, uint8_t* rgba8_out);
+float orc_gamma(float x); /* the pow(x, 1/2.2) of the post-process, as defined in oracle.cpp */
 
 #ifdef __cplusplus
 }

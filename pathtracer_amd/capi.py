@@ -38,7 +38,7 @@ KERNEL_NAMES = {K_GENERATE: "generate", K_EXTEND: "extend", K_SHADE: "shade", K_
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("iterations", C.c_uint64), ("bvh_nodes", C.c_uint32),
                 ("bvh_inner_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("bvh_build_ms", C.c_float),
-                ("bvh_refit_ms", C.c_float), ("pad_", C.c_uint32)]
+                ("bvh_refit_ms", C.c_float), ("trace_overruns", C.c_uint32)]
 
 
 class WaveSteps(C.Structure):

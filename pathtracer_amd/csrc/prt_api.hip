@@ -47,7 +47,7 @@ static hipError_t scratch_for_device(int device)
     return hipSuccess;
 }
 
-static constexpr uint32_t kStatWords    = 28;
+static constexpr uint32_t kStatWords    = 32;
 static constexpr uint32_t kCounterWords = 256;
 // UI cap is 10 (vkContext.cpp:266). The shader indexes scrambleArray[16] with 1 + bounce (pathRT.rgen:635-642, :703) and
 // takes Sobol dimensions 4 + 4*bounce .. +3 of the 64 kept here: both are defined up to 14 bounces.
@@ -884,6 +884,7 @@ static int render_ao(prt_context* c)
     }
     HIPCHK(c, hipGetLastError());
     c->lastPipe = 0;
+    p.lastSub   = 1;  // prt_read_hit_ids: the AO pass wrote the ids of its one iteration at offset 0
     return PRT_OK;
 }
 
@@ -1172,9 +1173,10 @@ int prt_get_stats(prt_context* c, prt_stats* s)
 {
     if(!c || !s) return PRT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    unsigned long long rays[2] = {0, 0};
+    unsigned long long rays[2] = {0, 0}, overruns = 0;
     HIPCHK(c, sync_all(c));
     HIPCHK(c, hipMemcpy(rays, c->stats, 16, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&overruns, c->stats + 28, 8, hipMemcpyDeviceToHost));
     s->rays            = rays[0] + rays[1];
     s->iterations      = c->iterations;
     s->bvh_nodes       = c->nNodes;
@@ -1182,7 +1184,7 @@ int prt_get_stats(prt_context* c, prt_stats* s)
     s->bvh_depth       = c->depth;
     s->bvh_build_ms    = c->buildMs;
     s->bvh_refit_ms    = c->refitMs;
-    s->pad_            = 0;
+    s->trace_overruns  = (uint32_t)(overruns > 0xffffffffull ? 0xffffffffull : overruns);
     return PRT_OK;
 }
 
@@ -1277,10 +1279,10 @@ int prt_trace_device(prt_context* c, const void* rays, size_t n, int any, void* 
     HIPCHK(c, hipEventRecord(e0, c->stream));
     if(any)
         hipLaunchKernelGGL(k_trace_batch<true>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc.bvh,
-                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune());
+                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
     else
         hipLaunchKernelGGL(k_trace_batch<false>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc.bvh,
-                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune());
+                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
     hipError_t e = hipGetLastError();
     if(e == hipSuccess) e = hipEventRecord(e1, c->stream);
     if(e == hipSuccess) e = hipEventSynchronize(e1);
@@ -1316,10 +1318,10 @@ int prt_trace_device_noalloc(prt_context* c, const void* rays, size_t n, int any
     HIPCHK(c, hipMemsetAsync(work, 0, PRT_NOALLOC_SCRATCH_BYTES, st));
     if(any)
         hipLaunchKernelGGL(k_trace_batch<true>, dim3(c->gridBatch), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
-                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune());
+                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
     else
         hipLaunchKernelGGL(k_trace_batch<false>, dim3(c->gridBatch), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
-                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune());
+                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
     HIPCHK(c, hipGetLastError());
     return PRT_OK;
 }

@@ -315,6 +315,40 @@ PRT_DEV float mitchell_netrevali(float v)  // :575-593
            / 6.0f;
 }
 
+// pow(x, 1/2.2) of the post-process (pathRTpostprocess.comp:48). GLSL leaves the rounding of pow open; this is the
+// definition the build uses, the same expression tree in the oracle and in the kernel, so the RGBA8 image is bit-exact:
+// x = m 2^e with m in [sqrt(1/2), sqrt(2)), log2 m by the atanh series in s = (m-1)/(m+1) up to s^9, y = log2(x) / 2.2,
+// 2^y = 2^n exp(f ln 2) with the Taylor polynomial of degree 7 on |f| <= 1/2 (relative error < 3e-7).
+// x <= 0 or NaN gives 0 (the UNORM store would clamp them to 0 anyway).
+PRT_DEV float gamma_fixed(float x)
+{
+    if(!(x > 0.0f)) return 0.0f;
+    if(x > 3.0e38f) return x;
+    float scale_e = 0.0f;
+    if(x < 1.17549435e-38f)
+    {
+        x       = x * 16777216.0f;
+        scale_e = -24.0f;
+    }
+    const int ix = __float_as_int(x);
+    int       e  = ((ix >> 23) & 0xff) - 127;
+    float     m  = __int_as_float((ix & 0x007fffff) | 0x3f800000);
+    if(m > 1.41421356f)
+    {
+        m = m * 0.5f;
+        e = e + 1;
+    }
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float z = s * s;
+    const float p = ((((z * 0.111111111f + 0.142857143f) * z + 0.2f) * z + 0.333333333f) * z) + 1.0f;
+    const float l = ((float)e + scale_e) + (2.88539008f * s) * p;
+    const float y = l * 0.454545455f;
+    const float n = __builtin_floorf(y + 0.5f);
+    const float t = (y - n) * 0.693147181f;
+    const float q = ((((((t * 1.98412698e-4f + 1.38888889e-3f) * t + 8.33333333e-3f) * t + 4.16666667e-2f) * t + 0.166666667f) * t + 0.5f) * t + 1.0f) * t + 1.0f;
+    return __int_as_float(__float_as_int(q) + ((int)n << 23));
+}
+
 // Bilinear / REPEAT fetch of an RGBA8 UNORM texture (sampler of vkTools.cpp:456-480), fp32 weights.
 struct TexDesc
 {
@@ -324,11 +358,15 @@ struct TexDesc
 PRT_DEV uint32_t tex_wrap(float f, uint32_t n)
 {
     const float m = f - __builtin_floorf(f / (float)n) * (float)n;
-    int         i = (int)m;
+    if(!(m == m)) return 0u;  // NaN coordinate: texel 0 (the float -> int conversion of a NaN is not defined)
+    int i = (int)m;
     if(i < 0)
         i += (int)n;
     if(i >= (int)n)
         i -= (int)n;
+    // |f| beyond 2^24 * n: one period does not bring the index home; stay inside the texture
+    if(i < 0) i = 0;
+    if(i >= (int)n) i = (int)n - 1;
     return (uint32_t)i;
 }
 PRT_DEV f3 tex_texel(const TexDesc& t, uint32_t x, uint32_t y)

@@ -63,7 +63,7 @@ struct FrameView
     uint8_t*  dead;   // pixel returned early in this iteration (primary miss)
     uint8_t*  nvert;  // terms stored for the pixel in this pass | 0x40 overwrite E | 0x80 reset E first
     unsigned long long* stats;  // [0] closest-hit rays, [1] any-hit rays, [2..3] nodes / triangles visited by
-                                // closest-hit rays, [4..5] by any-hit rays, [8..13] / [14..19] wave-step utilisation, [20..23] / [24..27] phase ticks (profiling level 2 only)
+                                // closest-hit rays, [4..5] by any-hit rays, [8..13] / [14..19] wave-step utilisation, [20..23] / [24..27] phase ticks (profiling level 2 only), [28] waves that hit the safety bound of trace_stream
 };
 
 PRT_DEV uint32_t wave_push(bool pred, uint32_t* counter)
@@ -133,6 +133,7 @@ PRT_DEV void flush_counts(const FrameView& f, uint32_t queued, uint32_t skippedL
         t = wave_sum(tc.tris);
     }
     if(blockIdx.x == 0 && threadIdx.x == 0 && queued) atomicAdd(f.stats + kind, (unsigned long long)queued);
+    if(tc.overrun && (threadIdx.x & 63) == 0) atomicAdd(f.stats + 28, 1ull);  // never expected: see trace_stream
     if((threadIdx.x & 63) == 0)
     {
         if(skipped) atomicAdd(f.stats + kind, ~(unsigned long long)skipped + 1ull);
@@ -789,9 +790,9 @@ __global__ void __launch_bounds__(256) k_postprocess(const float4* __restrict__ 
         c.z /= c.w;
         c.w /= c.w;
     }
-    c.x = __powf(c.x, 1.0f / 2.2f);
-    c.y = __powf(c.y, 1.0f / 2.2f);
-    c.z = __powf(c.z, 1.0f / 2.2f);
+    c.x = gamma_fixed(c.x);
+    c.y = gamma_fixed(c.y);
+    c.z = gamma_fixed(c.z);
     const float v[4] = {c.x, c.y, c.z, c.w};
     uint32_t    out  = 0;
     for(int k = 0; k < 4; ++k)
@@ -826,13 +827,15 @@ struct BatchIO
 template <bool ANY>
 __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) PRT_TRACE_ATTR k_trace_batch(BvhView bvh, const float4* __restrict__ rays,
                                                                  uint32_t n, float4* __restrict__ hits,
-                                                                 uint32_t* workCtr, TraceTune tune)
+                                                                 uint32_t* workCtr, TraceTune tune,
+                                                                 unsigned long long* stats)
 {
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     uint32_t            nskip = 0;
     TraceCount          tc    = {};
     BatchIO             io{rays, hits};
     trace_stream<ANY, false>(bvh, &stackLds[threadIdx.x], n, workCtr, tune, io, nskip, tc);
+    if(tc.overrun && (threadIdx.x & 63) == 0) atomicAdd(stats + 28, 1ull);
 }
 
 }  // namespace prt

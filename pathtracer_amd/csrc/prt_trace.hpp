@@ -75,6 +75,7 @@ struct TraceCount
     uint32_t wNode, lNode, wTri, lTri, wSetup, lSetup;
     // time stamps (s_memtime ticks, lane 0): spent in ray set-up / node phases / triangle phases / whole stream
     uint32_t cSetup, cNode, cTri, cTotal;
+    uint32_t overrun;  // the safety bound of trace_stream was reached: rays of this wave were dropped
 };
 
 // traversal knobs (wave-uniform kernel argument)
@@ -102,6 +103,11 @@ PRT_DEV void ray_prepare(const BvhView& bvh, f3 o, float tmin, f3 d, float tmax,
 {
     r.ox = o.x; r.oy = o.y; r.oz = o.z;
     r.tmin = tmin; r.tmax = tmax;
+    // A ray with a NaN in its origin or direction (the reference keeps NaN normals for corners without one, Model.cpp:171-175)
+    // hits nothing: every comparison of the triangle test fails. The slab test, however, drops NaNs (v_max / v_min return
+    // the other operand), so such a ray would walk the whole tree first. An infinite tmin closes every box instead: same
+    // result (a miss with t = tmax), no walk.
+    if((o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (d.x != d.x) | (d.y != d.y) | (d.z != d.z)) r.tmin = __builtin_inff();
     int kz = 0;
     if(gabs(d.y) > gabs(sel3(d.x, d.y, d.z, kz))) kz = 1;
     if(gabs(d.z) > gabs(sel3(d.x, d.y, d.z, kz))) kz = 2;
@@ -438,7 +444,12 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
         tc.field += (uint32_t)(now_ - tMark);                           \
         tMark = now_;                                                   \
     }
-    for(uint32_t guard = 0; guard < (1u << 24); ++guard)
+    // Every trip of this loop starts rays, advances them or finishes them, and a wave whose queue is exhausted and whose
+    // lanes are idle leaves through the `break` below. The bound is a safety net against a corrupted structure (a cycle
+    // in the node links): far above what any ray set needs (2^26 trips of >= 1 step); a wave that reaches it says so
+    // in tc.overrun, which the kernels add to the context's statistics (prt_stats.trace_overruns).
+    bool overrun = true;
+    for(uint32_t guard = 0; guard < (1u << 26); ++guard)
     {
         // ---- refill idle lanes from the queue
         const unsigned long long idleMask = __ballot(!active);
@@ -480,7 +491,11 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
         PRT_LAP(cSetup)
         if(nActive == 0)
         {
-            if(exhausted) break;
+            if(exhausted)
+            {
+                overrun = false;
+                break;
+            }
             continue;
         }
 
@@ -565,6 +580,7 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
         }
         PRT_LAP(cTri)
     }
+    if(overrun) tc.overrun = 1u;
     if(INSTR) tc.cTotal += (uint32_t)(__builtin_amdgcn_s_memtime() - tStart);
 #undef PRT_LAP
 }

@@ -158,8 +158,12 @@ bool Renderer::renderFrame()
         m_camera.setCameraMoved();
     }
     const prt_uniforms ubo = updateGraphicsUniforms();
+    m_lastUbo              = ubo;
     if(m_settings.RTX_ON && m_settings.iteration < (uint32_t)m_settings.samplesPerPixel)
     {
+        // the frame loop has the reference's image semantics: the shader restarts the sum when ubo.iteration <= 1
+        // (pathRT.rgen:649-654; AO.rgen likewise, and AO never gets past 0) and a primary miss overwrites the pixel
+        check(prt_set_flags(m_ctx, PRT_FLAG_LITERAL), "prt_set_flags");
         check(prt_set_uniforms(m_ctx, &ubo), "prt_set_uniforms");
         check(prt_render_iteration(m_ctx, m_settings.rtRenderingMode), "prt_render_iteration");
         return true;
@@ -189,6 +193,7 @@ void Renderer::render(uint32_t first, uint32_t n, uint32_t stride)
         ubo.lightE[1]    = m_light.getEmission().y;
         ubo.lightE[2]    = m_light.getEmission().z;
     }
+    check(prt_set_flags(m_ctx, 0), "prt_set_flags");  // additive sums: what sample sharding over GPUs needs
     check(prt_set_uniforms(m_ctx, &ubo), "prt_set_uniforms");
     check(prt_render(m_ctx, m_settings.rtRenderingMode, first, n, stride), "prt_render");
 }

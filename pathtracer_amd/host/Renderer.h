@@ -73,6 +73,7 @@ public:
     std::vector<uint8_t> postprocess();  // pathRTpostprocess.comp -> RGBA8
     prt_stats            stats();
     prt_context*         context() { return m_ctx; }
+    const prt_uniforms&  lastUniforms() const { return m_lastUbo; }  // the block of the last renderFrame()
 
     Settings       m_settings;
     CameraControls m_camera;
@@ -87,6 +88,7 @@ public:
 private:
     void         check(int rc, const char* what);
     prt_context* m_ctx = nullptr;
+    prt_uniforms m_lastUbo{};
 };
 
 bool writePPM(const std::string& path, const std::vector<uint8_t>& rgba, uint32_t w, uint32_t h);

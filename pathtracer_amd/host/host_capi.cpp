@@ -310,6 +310,54 @@ int prth_render_model(const prth_model* model, int device, uint32_t w, uint32_t 
     }
 }
 
+int prth_frame_loop(const prth_model* model, int device, uint32_t w, uint32_t h, const prth_settings* settings,
+                    const float eye[3], const float target[3], const prth_frame_event* events, size_t nEvents, uint32_t nFrames,
+                    prth_frame_record* records, float* accumOut, char* err, size_t errLen)
+{
+    if(!model || !eye || !target || !records || (nEvents && !events)) return -1;
+    try
+    {
+        const std::vector<Model> models(1, model->m);
+        Renderer                 r(device, w, h);
+        setup_view(r, settings, w, h, eye, target, nullptr, nullptr);
+        r.initRaytracing(models);
+        for(uint32_t f = 0; f < nFrames; ++f)
+        {
+            // the window's input handling runs before renderFrame (vkContext::mainLoop, vkContext.cpp:92-118)
+            for(size_t k = 0; k < nEvents; ++k)
+            {
+                const prth_frame_event& e = events[k];
+                if(e.frame != f) continue;
+                if(e.kind == PRTH_EVENT_MOVE_CAMERA)
+                    r.m_camera.updateMovements(1.0f, vec3(e.v[0], e.v[1], e.v[2]));  // WASD: vkWindow.cpp:127-134
+                else if(e.kind == PRTH_EVENT_MOVE_LIGHT)
+                    r.m_moveLight = true;  // Space: vkContext.cpp:1680-1705
+                else if(e.kind == PRTH_EVENT_SET_MODE)
+                    r.m_settings.rtRenderingMode = (int)e.v[0];  // KP1 / KP2
+                else
+                    throw std::runtime_error("prth_frame_loop: unknown event kind");
+            }
+            prth_frame_record& rec = records[f];
+            const uint32_t     before = r.m_settings.iteration;
+            rec.traced                = r.renderFrame() ? 1 : 0;
+            rec.ubo                   = r.lastUniforms();
+            rec.settings_iteration_before = before;
+            rec.settings_iteration_after  = r.m_settings.iteration;
+        }
+        if(accumOut)
+        {
+            const std::vector<float> a = r.readAccum();
+            memcpy(accumOut, a.data(), a.size() * sizeof(float));
+        }
+        return 0;
+    }
+    catch(const std::exception& e)
+    {
+        set_err(err, errLen, e.what());
+        return -2;
+    }
+}
+
 int prth_write_png(const char* path, const uint8_t* rgba, uint32_t w, uint32_t h)
 {
     if(!path || !rgba) return -1;

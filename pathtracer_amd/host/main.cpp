@@ -124,13 +124,16 @@ int main(int argc, char** argv)
             first = r.m_settings.iteration;
         }
         const uint32_t n = s.rtRenderingMode == 1 ? 1u : spp;  // spp = iterations rendered by THIS run
-        r.m_settings.samplesPerPixel = (int)(first + n);
-        r.render(first, n, 1);
-        r.m_settings.iteration = first + n;
+        // one iteration consumes numAArays Sobol indices (sobolIndex++ per aaRay, pathRT.rgen:970), so the frame loop
+        // advances by numAArays (vkContext.cpp:1033): the same stride here, or consecutive iterations would reuse samples
+        const uint32_t stride = s.rtRenderingMode == 0 && s.numAArays > 1 ? (uint32_t)s.numAArays : 1u;
+        r.m_settings.samplesPerPixel = (int)(first + n * stride);
+        r.render(first, n, stride);
+        r.m_settings.iteration = first + n * stride;
         if(!checkpoint.empty()) r.saveCheckpoint(checkpoint);
         const prt_stats st = r.stats();
         printf("%zu triangles, BVH %u nodes (%.1f ms), %llu rays, iterations %u..%u\n", ntri, st.bvh_nodes, st.bvh_build_ms,
-               (unsigned long long)st.rays, first, first + n - 1);
+               (unsigned long long)st.rays, first, first + (n - 1) * stride);
         if(!out.empty() && !writePPM(out, r.postprocess(), W, H)) fprintf(stderr, "cannot write %s\n", out.c_str());
         if(!pfm.empty() && !writePFM(pfm, r.readAccum(), W, H)) fprintf(stderr, "cannot write %s\n", pfm.c_str());
         if(!png.empty() && !writePNG(png, r.postprocess(), W, H)) fprintf(stderr, "cannot write %s\n", png.c_str());

@@ -17,8 +17,10 @@ EXPORTS = [
     "prth_model_num_materials", "prth_model_num_textures", "prth_model_vertices", "prth_model_indices",
     "prth_model_materials", "prth_model_texture", "prth_model_warnings", "prth_obj_dump_json", "prth_image_load",
     "prth_free", "prth_default_settings", "prth_camera_uniforms", "prth_render_obj", "prth_flatten_instances",
-    "prth_render_model", "prth_write_png", "prth_checkpoint_write", "prth_checkpoint_read",
+    "prth_render_model", "prth_write_png", "prth_checkpoint_write", "prth_checkpoint_read", "prth_frame_loop",
 ]
+
+EVENT_MOVE_CAMERA, EVENT_MOVE_LIGHT, EVENT_SET_MODE = 0, 1, 2
 
 
 class Settings(C.Structure):
@@ -77,6 +79,8 @@ def lib():
                                              C.POINTER(C.c_uint32), C.c_char_p, sz]
         L.prth_render_model.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(Settings), fp, fp, fp, fp,
                                         C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, vp, C.c_char_p, sz]
+        L.prth_frame_loop.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(Settings), fp, fp, vp, sz, C.c_uint32, vp,
+                                      vp, C.c_char_p, sz]
         L.prth_write_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
         i32p, u32p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
         L.prth_checkpoint_write.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
@@ -188,6 +192,39 @@ def render_model(model, width, height, settings, eye, target, light=None, first=
     if rc != 0:
         raise HostError(err.value.decode(errors="replace"))
     return accum
+
+
+class _FrameEvent(C.Structure):
+    _fields_ = [("frame", C.c_uint32), ("kind", C.c_int32), ("v", C.c_float * 3)]
+
+
+class _FrameRecord(C.Structure):
+    _fields_ = [("ubo", C.c_uint8 * 464), ("settings_iteration_before", C.c_uint32), ("settings_iteration_after", C.c_uint32),
+                ("traced", C.c_int32), ("pad_", C.c_uint32)]
+
+
+def frame_loop(model, width, height, settings, eye, target, events, n_frames, device=0):
+    """prth_frame_loop: n_frames of Renderer::renderFrame with the input `events` [(frame, kind, (x, y, z)), ...].
+    Returns (records, accum): records[f] = dict(ubo=464-byte block, before=, after=, traced=)."""
+    fp = C.POINTER(C.c_float)
+    a = lambda x: np.asarray(x, np.float32)
+    eye, target = a(eye), a(target)
+    ev = (_FrameEvent * max(1, len(events)))()
+    for k, (f, kind, v) in enumerate(events):
+        ev[k].frame, ev[k].kind = f, kind
+        ev[k].v[:] = [float(x) for x in v]
+    rec = (_FrameRecord * n_frames)()
+    accum = np.zeros((height, width, 4), np.float32)
+    err = C.create_string_buffer(1024)
+    rc = lib().prth_frame_loop(model.h, device, width, height, C.byref(settings), eye.ctypes.data_as(fp), target.ctypes.data_as(fp),
+                               ev, len(events), n_frames, rec, accum.ctypes.data_as(C.c_void_p), err, len(err))
+    if rc != 0:
+        raise HostError(err.value.decode(errors="replace"))
+    out = []
+    for r in rec:
+        ubo = np.frombuffer(bytes(r.ubo), dtype=uniforms.UBO_DTYPE)[0].copy()
+        out.append(dict(ubo=ubo, before=int(r.settings_iteration_before), after=int(r.settings_iteration_after), traced=bool(r.traced)))
+    return out, accum
 
 
 def write_png(path, rgba):

@@ -115,6 +115,25 @@ def test_trace_edge_cases(po):
     ctx.close()
 
 
+def test_nan_rays_are_misses_and_cost_nothing(po):
+    """A NaN in the origin or direction (the reference keeps NaN normals for corners without one): every comparison of the
+    triangle test fails, so the ray hits nothing — in the oracle after walking the tree, here without walking it."""
+    sc = scenes.conference_room(detail=0.4)
+    o, ctx = _pair(po, sc, 16, 16)
+    rays = _rays(4096, 3, 5.0)
+    nan = np.float32(np.nan)
+    for k in range(6):
+        (rays["o"] if k < 3 else rays["d"])[k::7, k % 3] = nan
+    g, c = ctx.trace(rays), o.trace_closest(rays)
+    assert g.tobytes() == c.tobytes()
+    bad = np.isnan(rays["o"]).any(axis=1) | np.isnan(rays["d"]).any(axis=1)
+    assert bad.sum() > 2000 and (g["prim"][bad] == MISS).all() and (g["t"][bad] == rays["tmax"][bad]).all()
+    assert (g["prim"][~bad] != MISS).any()
+    assert ((ctx.trace(rays, any_hit=True)["prim"] != MISS) == (o.trace_any(rays) == 1)).all()
+    assert ctx.stats().trace_overruns == 0
+    ctx.close()
+
+
 def test_grazing_self_hits(po):
     """Rays that leave a thin triangle almost in its plane (tests/helpers/grazing.py): closest and any-hit results of
     the GPU's BVH4 traversal equal the oracle's brute force over all triangles (hit definition)."""
@@ -244,6 +263,25 @@ def test_more_edge_cases_through_prt_render(po, case):
     nd = int((g.view(np.uint32) != acc.view(np.uint32)).any(axis=-1).sum())
     assert nd == 0, f"{nd} pixels differ"
     assert (ctx.read_hit_ids() == ids).all() and ctx.stats().rays == rays
+    ctx.close()
+
+
+def test_hit_ids_after_a_batched_render_then_ao(po):
+    """prt_read_hit_ids returns the ids of the LAST iteration: after a batched path render followed by an AO iteration
+    those are the AO pass's primary ids (pixel-centre rays), not the stale ids of the batch."""
+    sc = scenes.cornell_box()
+    W, H = 64, 48
+    o, ctx = _pair(po, sc, W, H)
+    ctx.set_iteration_batch(4)
+    ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=2, iteration=1))
+    ctx.render(capi.MODE_PATH, 1, 8)
+    u = uniforms.make_uniforms(sc, W, H, ao_rays=4, iteration=1)
+    ctx.set_uniforms(u)
+    ctx.clear_accum()
+    ctx.render_iteration(capi.MODE_AO)
+    acc, ids, _ = o.render(u, W, H, capi.MODE_AO, want_ids=True)
+    assert (ctx.read_hit_ids() == ids).all() and ctx.read_accum().tobytes() == acc.tobytes()
+    assert ctx.stats().trace_overruns == 0
     ctx.close()
 
 
@@ -426,7 +464,18 @@ def test_postprocess_matches_oracle(po):
     ctx.render_iteration(1)
     img = ctx.postprocess()
     ref = po.postprocess(ctx.read_accum(), W, H)
-    assert np.abs(img.astype(np.int32) - ref.astype(np.int32)).max() <= 1  # powf vs __powf: +-1 code value
+    assert img.tobytes() == ref.tobytes()  # byte output: exact (oracle and kernel share one definition of pow(x, 1/2.2))
+    # a path-traced image (radiance well above 1, zeros), and hand-made extremes: NaN, infinities, negative, w == 0
+    ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=3, iteration=1))
+    ctx.clear_accum()
+    ctx.render(0, 1, 3)
+    assert ctx.postprocess().tobytes() == po.postprocess(ctx.read_accum(), W, H).tobytes()
+    rng = np.random.default_rng(5)
+    acc = rng.uniform(0, 4, (H, W, 4)).astype(np.float32) * rng.choice([1e-30, 1e-3, 1, 1e3, 1e30], (H, W, 1)).astype(np.float32)
+    acc[0, :8, 0] = [np.nan, np.inf, -np.inf, -1.0, 0.0, -0.0, 1e-45, 3.4e38]
+    acc[1, :8, 3] = [0.0, np.nan, np.inf, -1.0, 1e-45, 3.4e38, 1.0, 2.0]
+    ctx.write_accum(acc)
+    assert ctx.postprocess().tobytes() == po.postprocess(acc, W, H).tobytes()
     ctx.close()
 
 

@@ -135,3 +135,100 @@ def test_cli_resume_and_png(tmp_path):
     px = np.frombuffer(ppm[ppm.index(b"255\n") + 4:], np.uint8).reshape(32, 48, 3)
     png = hostapi.load_image(t("a.png"))
     assert (png[..., :3] == px).all()
+
+
+# ---- the frame loop: vkContext::renderFrame / updateGraphicsUniforms (vkContext.cpp:124-231, 993-1060) ---------------------
+def _expected_frames(spp, aa, ao_rays, n_frames, events):
+    """The bookkeeping of vkContext.cpp:1028-1048 and :164, restated: per frame (ubo.iteration, iteration before, after,
+    traced, light captured before this frame's block was filled)."""
+    it, mode, camera_moved, move_light, light_is_camera = 1, 0, True, True, False
+    out = []
+    for f in range(n_frames):
+        for (ef, kind, v) in events:
+            if ef != f:
+                continue
+            if kind == hostapi.EVENT_MOVE_CAMERA:
+                camera_moved = True
+            elif kind == hostapi.EVENT_MOVE_LIGHT:
+                move_light = True
+            else:
+                mode = int(v[0])
+        before, ubo_it = it, 0  # UniformBufferObject's default: AO mode never writes it (vkContext.h:79)
+        if mode == 0 and it < spp:
+            ubo_it = it
+            it += aa
+        if mode == 1 and it < ao_rays:
+            it += 1
+        light_in_block = light_is_camera  # the block gets LAST frame's light; m_moveLight is served afterwards
+        if move_light:
+            light_is_camera, move_light = True, False
+        if camera_moved:
+            camera_moved, it = False, 1
+        out.append(dict(ubo_iteration=ubo_it, before=before, after=it, traced=it < spp, light_is_camera=light_in_block, mode=mode))
+    return out
+
+
+@pytest.mark.parametrize("aa", [1, 2])
+def test_frame_loop_follows_the_reference_bookkeeping(po, aa):
+    obj = os.path.join(G, "obj", "mixed.obj")
+    W, H, spp = 48, 32, 7
+    s = hostapi.default_settings(numIndicesBounces=2, samplesPerPixel=spp, numAArays=aa, lightSourceArea=0.3, numAOrays=4,
+                                 aoRayLength=1.2)
+    eye, target = (0.2, 1.1, 0.9), (0.0, 0.6, -0.4)
+    events = [(4, hostapi.EVENT_MOVE_CAMERA, (0, 0, 1)), (6, hostapi.EVENT_MOVE_LIGHT, (0, 0, 0)),
+              (13, hostapi.EVENT_SET_MODE, (1, 0, 0)), (13, hostapi.EVENT_MOVE_CAMERA, (1, 0, 0)),
+              (17, hostapi.EVENT_SET_MODE, (0, 0, 0)), (17, hostapi.EVENT_MOVE_CAMERA, (-1, 0, 0))]
+    n_frames = 24
+    with hostapi.open_model(obj) as m:
+        rec, gpu = hostapi.frame_loop(m, W, H, s, eye, target, events, n_frames)
+    exp = _expected_frames(spp, aa, 4, n_frames, events)
+    for f, (r, e) in enumerate(zip(rec, exp)):
+        assert (int(r["ubo"]["iteration"]), r["before"], r["after"], r["traced"]) == \
+               (e["ubo_iteration"], e["before"], e["after"], e["traced"]), f
+        # the light: identity until the first capture has been served, then inverse(view) of the frame that served it
+        inv_view = np.linalg.inv(r["ubo"]["view"].reshape(4, 4).T.astype(np.float64)).T.reshape(16)
+        if not e["light_is_camera"]:
+            assert r["ubo"]["lightTransform"].tobytes() == np.eye(4, dtype=np.float32).tobytes(), f
+    # iteration 1 twice after every (re)start, the counter stops one short of spp (vkContext.cpp:164), AO stays at 0
+    its = [int(r["ubo"]["iteration"]) for r in rec]
+    assert its[:3] == [1, 1, 1 + aa] and all(its[f] == 0 for f in range(13, 17))
+    assert rec[1]["ubo"]["lightTransform"].tobytes() != np.eye(4, dtype=np.float32).tobytes()  # one frame late
+    assert rec[7]["ubo"]["lightTransform"].tobytes() != rec[6]["ubo"]["lightTransform"].tobytes()  # Space at frame 6 shows at 7
+    assert rec[5]["ubo"]["view"].tobytes() != rec[3]["ubo"]["view"].tobytes()
+    # the image: the oracle fed with the traced frames' blocks, reference image semantics (E restarts when iteration <= 1)
+    scene = hostapi.load_model(obj)
+    o = po.Oracle(scene, seed=1)
+    acc = np.zeros((H, W, 4), np.float32)
+    for r, e in zip(rec, exp):
+        if r["traced"]:
+            acc, _, _ = o.render(r["ubo"], W, H, e["mode"], accum=acc, flags=1)
+    nan = np.isnan(gpu)
+    assert (nan == np.isnan(acc)).all() and np.where(nan, 0, gpu).tobytes() == np.where(nan, 0, acc).tobytes()
+
+
+def test_cli_aa_uses_the_frame_loops_stride(po, tmp_path):
+    """prt_render --aa N: iteration k starts at Sobol index 1 + k*N (vkContext.cpp:1033), as N renderFrame() calls would."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(hostapi.LIB_PATH), "prt_render")
+    obj = os.path.join(G, "obj", "mixed.obj")
+    pfm = tmp_path / "aa.pfm"
+    W, H, n, aa = 40, 24, 3, 3
+    subprocess.check_call([exe, obj, "--width", str(W), "--height", str(H), "--spp", str(n), "--aa", str(aa), "--bounces", "2",
+                           "--eye", "0.2", "1.1", "0.9", "--target", "0", "0.6", "-0.4", "--out", "", "--pfm", str(pfm)])
+    s = hostapi.default_settings(numIndicesBounces=2, samplesPerPixel=n, numAArays=aa)
+    _, ubo = hostapi.render_obj(obj, W, H, s, (0.2, 1.1, 0.9), (0.0, 0.6, -0.4), first=1, n=1)
+    o = po.Oracle(hostapi.load_model(obj), seed=1)
+    acc = np.zeros((H, W, 4), np.float32)
+    for k in range(n):
+        u = ubo.copy()
+        u["iteration"] = 1 + k * aa
+        acc, _, _ = o.render(u, W, H, 0, accum=acc)
+    raw = open(pfm, "rb").read()
+    hdr_end = 0
+    for _ in range(3):
+        hdr_end = raw.index(b"\n", hdr_end) + 1
+    img = np.frombuffer(raw[hdr_end:], "<f4").reshape(H, W, 3)[::-1]  # PFM rows are bottom-up; colour / w
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ref = acc[..., :3] / acc[..., 3:4]
+    ok = np.isfinite(ref).all(axis=-1) & np.isfinite(img).all(axis=-1)
+    assert ok.mean() > 0.5 and np.allclose(img[ok], ref[ok], rtol=0, atol=0)

@@ -37,10 +37,26 @@ fetch, nf = per_kernel("prof_fetch/fetch_results.db", ["FETCH_SIZE"])
 write, nw = per_kernel("prof_write/write_results.db", ["WRITE_SIZE"])
 tcc, nt = per_kernel("prof_tcc/tcc_results.db", [])
 sq, ns = per_kernel("prof_sq/sq_results.db", [])
+try:
+    tcp, ntcp = per_kernel("prof_tcp/tcp_results.db", [])
+except Exception:
+    tcp, ntcp = {}, {}
+# launch duration and rays per launch of every kernel (kernel trace; rays from the bench line of the traced run)
+avg_us = {short(n): a for n, a in db.execute("select name,average from top_kernels")}
+# Bytes of coalesced (streamed) 16-byte-per-lane reads per ray of the traversal kernels: queue slot 4 + ray record 32
+# (+ 16 for the radiance term a visible shadow ray copies): FETCH_SIZE counts these 128-byte requests at 64 B
+# (MI355X_MICROARCH.md), while the divergent 64-byte gathers of nodes and triangles are counted exactly
+# (tools/calib_fetch.sh: 65.7 B per 64-byte record, 1.05 TCP->L2 requests). So traffic = FETCH_SIZE + WRITE_SIZE +
+# half the streamed reads.
+STREAMED_READ_B_PER_RAY = 40.0
+L1_MISS_CEILING = 0.41  # lines per clock per CU a CU can pull from L2 with divergent gathers (tools/ubench_gather.hip)
 out.append("\n## PMC passes (separate runs: FETCH_SIZE | WRITE_SIZE | TCC_HIT/MISS | SQ_*)\n")
-out.append("FETCH_SIZE / WRITE_SIZE are reported in KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE counts 128-byte "
-           "requests at 64 B for 16-byte-per-lane loads on gfx950, so the `HBM read` column is FETCH_SIZE x 2. The counters sit at the L2's "
-           "fabric side, so Infinity-Cache hits are included: this is traffic leaving L2, an upper bound on HBM traffic.\n")
+out.append("FETCH_SIZE / WRITE_SIZE are reported in KiB. Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE counts the 128-byte requests of "
+           "wide coalesced loads at 64 B; calibrated on this access pattern (tools/calib_fetch.sh, gpurun_out/r02/calib_fetch.log) it counts "
+           "divergent 64-byte gathers exactly (65.7 B per 64-byte record from a 2 GB table, 1.05 TCP->L2 requests per record). The "
+           "`read MB/launch (x2)` column is therefore an upper bound; `pmc_traffic.json` uses FETCH_SIZE + WRITE_SIZE + half the streamed "
+           "reads of the traversal kernels (40 B per ray). The counters sit at the L2's fabric side, so Infinity-Cache hits are included: "
+           "traffic leaving L2, an upper bound on HBM traffic.\n")
 out.append("| kernel | launches | FETCH_SIZE KiB/launch (raw) | read MB/launch (x2) | WRITE_SIZE KiB/launch | L2 hit rate | VALU busy (SQ_ACTIVE_INST_VALU*4/SQ_BUSY_CYCLES... see below) |\n|---|---:|---:|---:|---:|---:|---:|")
 for k in ["prt::k_shadow_extend<false>", "prt::k_extend<false>", "prt::k_shadow<false>", "prt::k_shade", "prt::k_generate", "prt::k_resolve"]:
     if k not in fetch: continue
@@ -50,9 +66,25 @@ for k in ["prt::k_shadow_extend<false>", "prt::k_extend<false>", "prt::k_shadow<
     valu = s.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / max(1.0, s.get("SQ_WAVE_CYCLES", 0.0) * 4.0) if False else 0
     util = s.get("SQ_ACTIVE_INST_VALU", 0.0) / max(1.0, s.get("SQ_WAVE_CYCLES", 1.0))
     out.append(f"| `{k}` | {nf[k]} | {f:.0f} | {f*1024*2/1e6:.2f} | {w:.0f} | {h/max(1.0,h+m):.3f} | {util:.3f} |")
-    traffic[k.replace("prt::", "").split("<")[0]] = {"hbm_bytes_per_launch": round(f * 1024 * 2 + w * 1024), "fetch_kib_raw": round(f, 1),
-                                                       "write_kib": round(w, 1), "l2_hit_rate": round(h / max(1.0, h + m), 4),
-                                                       "valu_active_per_wave_cycle": round(util, 4)}
+    e = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1), "l2_hit_rate": round(h / max(1.0, h + m), 4),
+         "valu_active_per_wave_cycle": round(util, 4),
+         "wait_any_per_wave_cycle": round(s.get("SQ_WAIT_ANY", 0.0) / max(1.0, s.get("SQ_WAVE_CYCLES", 1.0)), 4),
+         "trace_avg_us": round(avg_us.get(k, 0.0), 2)}
+    # SIMD busy: a wave64 VALU instruction holds a SIMD-32 for 2 cycles; 1024 SIMDs; clock from GRBM_GUI_ACTIVE (sum of 8 XCDs)
+    if avg_us.get(k) and s.get("SQ_INSTS_VALU") and s.get("GRBM_GUI_ACTIVE") and ns.get(k):
+        cyc = s["GRBM_GUI_ACTIVE"] / 8.0 / ns[k]  # shader cycles per launch
+        e["valu_busy_simd"] = round(s["SQ_INSTS_VALU"] / ns[k] * 2.0 / (cyc * 1024.0), 4)
+        e["clock_GHz"] = round(cyc / (avg_us[k] * 1e3), 3)
+    if k in tcp and ntcp.get(k):
+        t = tcp[k]
+        req = t.get("TCP_TCC_READ_REQ_sum", 0.0) / ntcp[k]
+        e["tcp_tcc_read_req_per_launch"] = round(req)
+        e["tcp_tcc_read_latency_cycles"] = round(t.get("TCP_TCC_READ_REQ_LATENCY_sum", 0.0) / max(1.0, t.get("TCP_TCC_READ_REQ_sum", 1.0)), 1)
+        if t.get("GRBM_GUI_ACTIVE"):
+            cyc = t["GRBM_GUI_ACTIVE"] / 8.0 / ntcp[k]
+            e["l1_miss_lines_per_clk_per_cu"] = round(req / cyc / 256.0, 4)
+            e["l1_miss_ceiling_lines_per_clk_per_cu"] = L1_MISS_CEILING
+    traffic[k.replace("prt::", "").split("<")[0]] = e
 out.append("\nLast column = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (fraction of resident-wave cycles in which the wave is issuing VALU work).\n")
 out.append("### raw SQ counters (sum over launches)\n")
 for k in ["prt::k_shadow_extend<false>", "prt::k_extend<false>", "prt::k_shadow<false>", "prt::k_shade"]:
@@ -65,10 +97,21 @@ if os.path.exists(bj):
         r = json.load(open(bj))["roofline"]
         k = r["kernel"].split(" ")[0]
         if k in traffic:
-            traffic[k]["rays_per_launch"] = r["standalone"]["rays_per_launch"]
-            traffic[k]["hbm_bytes_per_ray"] = round(traffic[k]["hbm_bytes_per_launch"] / r["standalone"]["rays_per_launch"], 2)
+            e, n = traffic[k], r["rays_per_launch"]
+            e["rays_per_launch"] = n
+            e["fetch_correction"] = "1 (gathers, calibrated) + 20 B per ray for the half-counted streamed reads"
+            e["hbm_bytes_per_launch"] = round(e["fetch_kib_raw"] * 1024 + e["write_kib"] * 1024 + 0.5 * STREAMED_READ_B_PER_RAY * n)
+            e["hbm_bytes_per_ray"] = round(e["hbm_bytes_per_launch"] / n, 2)
+            e["hbm_GB/s_at_trace_duration"] = round(e["hbm_bytes_per_launch"] / (e["trace_avg_us"] * 1e-6) / 1e9, 1)
+            e["hbm_frac_of_8TB/s"] = round(e["hbm_GB/s_at_trace_duration"] / 8000.0, 4)
+            if "tcp_tcc_read_req_per_launch" in e:
+                e["tcp_tcc_read_req_per_ray"] = round(e["tcp_tcc_read_req_per_launch"] / n, 2)
     except Exception as e:
         print("no launch size:", e)
+traffic["_tag"] = tag
+out.append("\n## Derived per kernel (profiles/pmc_traffic.json)\n")
+out.append("```\n" + json.dumps(traffic, indent=1) + "\n```")
+open(os.path.join(P, f"{tag}_rocprof_summary.md"), "w").write("\n".join(out) + "\n")
 json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 if os.path.exists(bj):
     open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w").write(open(bj).read())

@@ -121,6 +121,17 @@ int main(int argc, char** argv)
     for(auto& v : h) v = (s = s * 1664525u + 1013904223u);
     CHECK(hipMemcpy(table, h.data(), tableBytes, hipMemcpyHostToDevice));
     printf("table %zu MB, %d blocks of 256 threads (6 waves per SIMD)\n", mb, blocks);
+    if(argc > 2)  // one variant only (PMC calibration: records read = 1536 blocks x 256 lanes x 2050 rounds)
+    {
+        switch(argv[2][0])
+        {
+        case 'A': run<0>("A  lane: 4 x 16 B of its own 64-B record", table, tableBytes, 64, 4, out, blocks); break;
+        case 'C': run<2>("C  lane: 16 B of its own record, 1 load", table, tableBytes, 64, 1, out, blocks); break;
+        case 'D': run<3>("D  lane: 5 x 16 B of its own 80-B record", table, tableBytes, 80, 5, out, blocks); break;
+        default: run<4>("E  oct: 8 records of 128 B, 16 B per lane", table, tableBytes, 128, 8, out, blocks); break;
+        }
+        return 0;
+    }
     run<0>("A  lane: 4 x 16 B of its own 64-B record", table, tableBytes, 64, 4, out, blocks);
     run<1>("B  quad: 4 records, 16 B per lane per load", table, tableBytes, 64, 4, out, blocks);
     run<2>("C  lane: 16 B of its own record, 1 load", table, tableBytes, 64, 1, out, blocks);
