@@ -1538,6 +1538,63 @@ float orc_gamma(float x)
     return bits_float(float_bits(q) + ((int)n << 23));
 }
 
+// The shading helpers one by one, for the identity tests (unit tier) and for the transcription audit
+// against the shader text compiled with glm (oracle/make_glsl_audit.py). `which`: ORC_H_* of oracle.h; `in` / `out`:
+// the function's arguments / results as flat float arrays, in the order of the GLSL signature.
+int orc_helper(int which, const float* in, float* out)
+{
+    auto v3 = [&](int k) { return V3(in[k], in[k + 1], in[k + 2]); };
+    auto put3 = [&](int k, vec3 v) { out[k] = v.x; out[k + 1] = v.y; out[k + 2] = v.z; };
+    switch(which)
+    {
+    case ORC_H_FORM_BASIS:
+    {
+        const mat3 m = formBasis(v3(0));
+        put3(0, m.c0); put3(3, m.c1); put3(6, m.c2);
+        return 9;
+    }
+    case ORC_H_SAMPLE_LIGHT:  // in: lightSize[2], lightTransform[16], prng[2]
+    {
+        prt_uniforms u;
+        memset(&u, 0, sizeof u);
+        u.lightSize[0] = in[0]; u.lightSize[1] = in[1];
+        memcpy(u.lightTransform, in + 2, 64);
+        float pdf = 0.0f;
+        vec3  p   = V3(0.0f);
+        sampleLight(u, pdf, p, vec2{in[18], in[19]});
+        out[0] = pdf; put3(1, p);
+        return 4;
+    }
+    case ORC_H_GGX_DISTRIBUTION: out[0] = GGX_Distribution(v3(0), in[3]); return 1;
+    case ORC_H_GGX_G1: out[0] = GGX_G1(v3(0), v3(3), in[6]); return 1;
+    case ORC_H_FRESNEL_DIELECTRIC: out[0] = GGX_FresnelDielectric(in[0], in[1], in[2]); return 1;
+    case ORC_H_SCHLICK_FRESNEL: put3(0, GGX_SchlickFresnel(v3(0), in[3])); return 3;
+    case ORC_H_SMITH_MASKING: out[0] = GGX_SmithMasking(v3(0), v3(3), in[6]); return 1;
+    case ORC_H_SMITH_MASKING_SHADOWING: out[0] = GGX_SmithMaskingShadowing(v3(0), v3(3), in[6]); return 1;
+    case ORC_H_SAMPLE_VNDF: put3(0, GGX_SampleVNDF(v3(0), in[3], vec2{in[4], in[5]})); return 3;
+    case ORC_H_REFRACT:
+    {
+        vec3 wt = V3(0.0f);
+        out[0]  = refract_(v3(0), v3(3), wt, in[6]) ? 1.0f : 0.0f;
+        put3(1, wt);
+        return 4;
+    }
+    case ORC_H_PRIMARY_RAY:  // in: projViewInverse[16], px, py, w, h, var[2]
+    {
+        prt_uniforms u;
+        memset(&u, 0, sizeof u);
+        memcpy(u.projViewInverse, in, 64);
+        vec3 Ro, Rd;
+        getPrimaryRay(u, (uint32_t)in[16], (uint32_t)in[17], (uint32_t)in[18], (uint32_t)in[19], vec2{in[20], in[21]}, Ro, Rd);
+        put3(0, Ro); put3(3, Rd);
+        return 6;
+    }
+    case ORC_H_MITCHELL: out[0] = mitchellNetrevali(in[0]); return 1;
+    case ORC_H_MITCHELL_WEIGHT: out[0] = getMitchellWeight(vec2{in[0], in[1]}); return 1;
+    default: return -1;
+    }
+}
+
 // pathRTpostprocess.comp:38-51
 void orc_postprocess(const float* accum, uint32_t w, uint32_t h, uint8_t* out)
 {

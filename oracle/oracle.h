@@ -92,7 +92,27 @@ uint64_t orc_render(const orc_scene*, const prt_uniforms* ubo, uint32_t w, uint3
 
 /* pathRTpostprocess.comp:38-51 over the full image. out = RGBA8. */
 void orc_postprocess(const float* accum, uint32_t w, uint32_t h, uint8_t* rgba8_out);
-float orc_gamma(float x); /* the pow(x, 1/2.2) of the post-process, as defined in oracle.cpp */
+float orc_gamma(float x);
+/* the shading helpers of pathRT.rgen one at a time (identity tests, transcription audit); returns the number of floats
+ * written to `out`, -1 for an unknown `which` */
+enum
+{
+    ORC_H_FORM_BASIS = 0,          /* :176-197  in n[3]                                   out mat3 (columns T, B, n) */
+    ORC_H_SAMPLE_LIGHT,            /* :304-309  in lightSize[2], lightTransform[16], prng[2]   out pdf, p[3] */
+    ORC_H_GGX_DISTRIBUTION,        /* :331-341  in wm[3], alpha */
+    ORC_H_GGX_G1,                  /* :343-356  in wv[3], wm[3], alpha */
+    ORC_H_FRESNEL_DIELECTRIC,      /* :435-463  in cosThetaI, ni, nt */
+    ORC_H_SCHLICK_FRESNEL,         /* :465-469  in r0[3], radians                         out vec3 */
+    ORC_H_SMITH_MASKING,           /* :471-478  in wi[3], wo[3], alpha */
+    ORC_H_SMITH_MASKING_SHADOWING, /* :480-490  in wi[3], wo[3], alpha */
+    ORC_H_SAMPLE_VNDF,             /* :492-509  in wo[3], alpha, rnd[2]                   out vec3 */
+    ORC_H_REFRACT,                 /* :511-526  in wi[3], wn[3], eta                      out ok, wt[3] */
+    ORC_H_PRIMARY_RAY,             /* :541-567  in projViewInverse[16], px, py, w, h, var[2]   out origin[3], dir[3] */
+    ORC_H_MITCHELL,                /* :575-593  in v */
+    ORC_H_MITCHELL_WEIGHT,         /* :595-598  in offset[2] */
+    ORC_H_COUNT
+};
+int orc_helper(int which, const float* in, float* out); /* the pow(x, 1/2.2) of the post-process, as defined in oracle.cpp */
 
 #ifdef __cplusplus
 }

@@ -190,3 +190,28 @@ def postprocess(accum, w, h):
     a = np.ascontiguousarray(accum, dtype=np.float32)
     lib().orc_postprocess(_ptr(a), w, h, _ptr(out))
     return out
+
+
+# ---- the shading helpers one at a time (oracle.h: orc_helper) -------------------------------------------------------
+(H_FORM_BASIS, H_SAMPLE_LIGHT, H_GGX_DISTRIBUTION, H_GGX_G1, H_FRESNEL_DIELECTRIC, H_SCHLICK_FRESNEL, H_SMITH_MASKING,
+ H_SMITH_MASKING_SHADOWING, H_SAMPLE_VNDF, H_REFRACT, H_PRIMARY_RAY, H_MITCHELL, H_MITCHELL_WEIGHT) = range(13)
+HELPER_IO = {H_FORM_BASIS: (3, 9), H_SAMPLE_LIGHT: (20, 4), H_GGX_DISTRIBUTION: (4, 1), H_GGX_G1: (7, 1),
+             H_FRESNEL_DIELECTRIC: (3, 1), H_SCHLICK_FRESNEL: (4, 3), H_SMITH_MASKING: (7, 1),
+             H_SMITH_MASKING_SHADOWING: (7, 1), H_SAMPLE_VNDF: (6, 3), H_REFRACT: (7, 4), H_PRIMARY_RAY: (22, 6),
+             H_MITCHELL: (1, 1), H_MITCHELL_WEIGHT: (2, 1)}
+
+
+def helper(which, inputs, fn=None):
+    """Rows of `inputs` (n x n_in float32) through helper `which`; returns n x n_out float32. `fn`: another library's
+    function with orc_helper's signature (the transcription audit)."""
+    if fn is None:
+        fn = lib().orc_helper
+    fn.argtypes, fn.restype = [C.c_int, C.c_void_p, C.c_void_p], C.c_int
+    n_in, n_out = HELPER_IO[which]
+    a = np.ascontiguousarray(np.atleast_2d(np.asarray(inputs, np.float32)))
+    assert a.shape[1] == n_in
+    out = np.zeros((len(a), n_out), np.float32)
+    for k in range(len(a)):
+        if fn(which, a[k].ctypes.data, out[k].ctypes.data) != n_out:
+            raise RuntimeError(f"helper {which}")
+    return out
