@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing "
                                                        "the N > 1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: ranks beyond the GPU count share cuda:0")
+    ap.add_argument("--dump-accum", default="", help="rank 0 saves the summed accumulation image of the timed region (.npy)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,7 +119,7 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
 
-    from pathtracer_amd import capi, scenes, uniforms
+    from pathtracer_amd import capi, scenes, sharding, uniforms
 
     W, H, K, WU = args.width, args.height, args.steps, args.warmup
     t0 = time.time()
@@ -144,6 +145,9 @@ def main():
     if args.pipes:
         ctx.set_pipeline_depth(args.pipes)
     in_flight = ctx.pipeline_depth()
+    # sample sharding: K iterations per GPU (weak scaling) = iterations 1 .. K*N dealt round-robin
+    it_first, it_n, it_stride = sharding.iteration_shard(rank, n_gpus, K * n_gpus)
+    assert (it_first, it_n, it_stride) == (1 + rank, K, n_gpus)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
     ctx.bind_accum(accum.data_ptr())
 
@@ -177,15 +181,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    ctx.render(capi.MODE_PATH, 1 + rank, K, n_gpus)
+    ctx.render(capi.MODE_PATH, it_first, it_n, it_stride)
     ctx.sync()
-    if dist:
-        dist.all_reduce(accum, op=dist.ReduceOp.SUM)
+    sharding.sum_reduce_(accum, dist)  # the one collective of the path: RCCL all-reduce(sum) of W*H*4 floats
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
+    if args.dump_accum and rank == 0:
+        np.save(args.dump_accum, accum.cpu().numpy())
 
     stats = ctx.stats()
     rays = torch.tensor([float(stats.rays)], dtype=torch.float64, device=f"cuda:{local}")

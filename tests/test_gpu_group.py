@@ -106,3 +106,47 @@ def test_group_rccl_plumbing_single_member():
         g.close()
     finally:
         del os.environ["PRT_GROUP_FORCE_RCCL"]
+
+
+def test_bench_two_ranks_on_one_gpu_equal_a_single_process(tmp_path):
+    """The N > 1 code path of bench.py — one process per rank, pathtracer_amd.sharding's round-robin deal, ONE all-reduce —
+    run as the driver runs it (torch.distributed.run), with two ranks sharing GPU 0 and the gloo backend because the box
+    has one GPU. The summed image equals a single-process render of the same iterations up to fp32 summation order.
+    What this cannot cover: the RCCL transport between two distinct devices."""
+    import socket
+    import subprocess
+    import sys
+
+    from pathtracer_amd import uniforms
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    W, H, K = 192, 108, 5
+    out = tmp_path / "sum.npy"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(K), "--warmup", "1",
+           "--backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-profile", "--width", str(W), "--height", str(H),
+           "--detail", "0.3", "--dump-accum", str(out)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    import json
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["parallelism"] == "spp-sharded x2"
+    got = np.load(out)
+    sc = scenes.conference_room(seed=2, detail=0.3)
+    with capi.Context(W, H) as ctx:
+        ctx.set_scene(sc)
+        ctx.set_seed(2)
+        ctx.build_accel()
+        ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=5, spp=1024, iteration=1, light_area=0.02))
+        ctx.render(capi.MODE_PATH, 1, 2 * K)
+        ref = ctx.read_accum()
+        assert line["config"]["rays_total"] == ctx.stats().rays
+    assert (got[..., 3] == ref[..., 3]).all()  # vertex counts: exact
+    num = ((got - ref)[..., :3].astype(np.float64) ** 2).mean()
+    den = (ref[..., :3].astype(np.float64) ** 2).mean()
+    assert num / den < 1e-10
