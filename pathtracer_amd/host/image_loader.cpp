@@ -86,7 +86,10 @@ struct Huffman
     }
 };
 
-bool inflate_raw(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
+// `limit`: the decoder stops (successfully) once it has produced this many bytes. A PNG knows how many bytes its
+// scanlines take; what a stream holds beyond them is never looked at (the reference's decoder ignores it too), and a
+// decompression bomb costs no more memory than the image it claims to be.
+bool inflate_raw(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t limit)
 {
     static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint16_t lext[29]  = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -105,8 +108,10 @@ bool inflate_raw(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
             const uint32_t len = src[br.pos] | (src[br.pos + 1] << 8), nlen = src[br.pos + 2] | (src[br.pos + 3] << 8);
             br.pos += 4;
             if((len ^ 0xffffu) != nlen || br.pos + len > n) return false;
-            out.insert(out.end(), src + br.pos, src + br.pos + len);
+            const size_t take = out.size() + len > limit ? limit - out.size() : (size_t)len;
+            out.insert(out.end(), src + br.pos, src + br.pos + take);
             br.pos += len;
+            if(out.size() >= limit) return true;
         }
         else if(type == 1 || type == 2)
         {
@@ -164,7 +169,10 @@ bool inflate_raw(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
                 const int sym = lit.decode(br);
                 if(sym < 0 || br.bad) return false;
                 if(sym < 256)
+                {
                     out.push_back((uint8_t)sym);
+                    if(out.size() >= limit) return true;
+                }
                 else if(sym == 256)
                     break;
                 else
@@ -177,7 +185,8 @@ bool inflate_raw(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
                     const size_t d = dbase[ds] + br.bits(dext[ds]);
                     if(d > out.size()) return false;
                     const size_t from = out.size() - d;
-                    for(int k = 0; k < len; ++k) out.push_back(out[from + k]);
+                    for(int k = 0; k < len && out.size() < limit; ++k) out.push_back(out[from + k]);
+                    if(out.size() >= limit) return true;
                 }
             }
         }
@@ -188,11 +197,11 @@ bool inflate_raw(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
     return true;
 }
 
-bool zlib_inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
+bool zlib_inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t limit)
 {
     if(n < 6) return false;
     if((src[0] & 0x0f) != 8 || ((src[0] << 8) | src[1]) % 31 != 0 || (src[1] & 0x20)) return false;
-    return inflate_raw(src + 2, n - 2, out);  // the Adler-32 trailer is not verified (neither does the reference)
+    return inflate_raw(src + 2, n - 2, out, limit);  // the Adler-32 trailer is not verified (neither does the reference)
 }
 
 // ---- PNG -----------------------------------------------------------------------------------------------------
@@ -287,12 +296,28 @@ bool load_png(const std::vector<uint8_t>& f, Image& img)
     if(!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) return false;
     if(ctype == 3 && (depth == 16 || plte.empty())) return false;
     if(interlace > 1) return false;
+    if((uint64_t)w * h > (1ull << 28)) return false;  // 2^28 pixels: beyond any texture, and it bounds every allocation below
+    const int bitsPerPixel = depth * chans;
+    // bytes the scanlines (filter byte + packed samples) of the whole image take: known before anything is allocated
+    size_t expected = 0;
+    {
+        auto lines = [&](uint32_t pw, uint32_t ph) { return pw && ph ? ((size_t)((uint64_t)pw * bitsPerPixel + 7) / 8 + 1) * ph : (size_t)0; };
+        if(!interlace)
+            expected = lines(w, h);
+        else
+        {
+            static const uint32_t ax0[7] = {0, 4, 0, 2, 0, 1, 0}, ay0[7] = {0, 0, 4, 0, 2, 0, 1}, adx[7] = {8, 8, 4, 4, 2, 2, 1},
+                                  ady[7] = {8, 8, 8, 4, 4, 2, 2};
+            for(int p = 0; p < 7; ++p)
+                expected += lines(w > ax0[p] ? (w - ax0[p] + adx[p] - 1) / adx[p] : 0, h > ay0[p] ? (h - ay0[p] + ady[p] - 1) / ady[p] : 0);
+        }
+    }
     std::vector<uint8_t> raw;
-    if(!zlib_inflate(idat.data(), idat.size(), raw)) return false;
+    if(!zlib_inflate(idat.data(), idat.size(), raw, expected)) return false;
+    if(raw.size() < expected) return false;  // cut short: nothing is allocated for an image that is not there
 
     // samples (one uint16 per sample, native value) of the whole image
     std::vector<uint16_t> smp((size_t)w * h * chans, 0);
-    const int             bitsPerPixel = depth * chans;
     const int             bpp          = bitsPerPixel >= 8 ? bitsPerPixel / 8 : 1;
     auto scatter = [&](const std::vector<uint8_t>& pix, size_t stride, uint32_t pw, uint32_t ph, uint32_t x0, uint32_t y0,
                        uint32_t dx, uint32_t dy) {
@@ -419,10 +444,11 @@ bool load_tga(const std::vector<uint8_t>& f, Image& img)
     size_t pos = 18 + (size_t)idLen;
     const int cmapBytes = (cmapBits + 7) / 8;
     const uint8_t* cmap = nullptr;
+    if(base == 1 && cmapLen == 0) return false;  // indices into an empty palette
     if(cmapType)
     {
         if(pos + (size_t)cmapLen * cmapBytes > f.size()) return false;
-        cmap = &f[pos];
+        cmap = f.data() + pos;
         pos += (size_t)cmapLen * cmapBytes;
     }
     const int bytes = (bits + 7) / 8;

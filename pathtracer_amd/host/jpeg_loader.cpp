@@ -388,7 +388,7 @@ struct Decoder
             const int t    = decodeSymbol(dc[c.td]);
             const int diff = t > 0 ? receiveExtend(t > 16 ? 16 : t) : 0;
             c.dcPred += diff;
-            blk[0] = (int16_t)(c.dcPred << al);
+            blk[0] = (int16_t)(c.dcPred * (1 << al));  // (a shift of a negative value is undefined before C++20)
         }
         else if(getBit())
             blk[0] = (int16_t)(blk[0] + (int16_t)(1 << al));
@@ -429,7 +429,7 @@ struct Decoder
                 else
                 {
                     k += run;
-                    blk[natural_of(k++)] = (int16_t)(receiveExtend(size) << al);
+                    blk[natural_of(k++)] = (int16_t)(receiveExtend(size) * (1 << al));
                 }
             } while(k <= se);
             return true;

@@ -333,3 +333,35 @@ def test_checkpoint_file_round_trip(tmp_path):
             hostapi.checkpoint_read(bad)
     with pytest.raises(hostapi.HostError):
         hostapi.checkpoint_read(str(tmp_path / "missing.ckpt"))
+
+
+def test_malformed_textures_fall_back_without_huge_allocations(tmp_path):
+    """a PNG header that claims 2^24 x 2^24 pixels, a stream that inflates far beyond its image, a colour-mapped
+    TGA without palette, truncated files: each is refused (Model then uses the reference's 1x1 white texture, Model.cpp:352-359)
+    and none of them makes the decoder allocate what the header claims."""
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    def png(w, h, idat, ctype=6, depth=8):
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + chunk(b"IDAT", idat) + chunk(b"IEND", b"")
+
+    good_raw = b"".join(b"\0" + bytes([10 * y, 20, 30, 255] * 3) for y in range(2))
+    cases = {
+        "huge_header.png": png(1 << 24, 1 << 24, zlib.compress(good_raw)),
+        "big_header_small_data.png": png(16000, 16000, zlib.compress(good_raw)),
+        "truncated_stream.png": png(3, 2, zlib.compress(good_raw)[:-9]),
+        "nopalette.tga": bytes([0, 1, 1, 0, 0, 0, 0, 24, 0, 0, 0, 0, 2, 0, 2, 0, 8, 0]) + b"\0\1\2\3",
+        "short.tga": bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 0, 4, 0, 24, 0]) + b"\0" * 5,
+    }
+    for name, data in cases.items():
+        (tmp_path / name).write_bytes(data)
+        assert hostapi.load_image(str(tmp_path / name)) is None, name
+    # a bomb: 3 x 2 pixels, but the stream inflates to 64 MiB -> decoded from its first 26 bytes, the rest never produced
+    (tmp_path / "bomb.png").write_bytes(png(3, 2, zlib.compress(good_raw + b"\0" * (64 << 20))))
+    img = hostapi.load_image(str(tmp_path / "bomb.png"))
+    assert img is not None and img.shape == (2, 3, 4) and img[1, 0].tolist() == [10, 20, 30, 255]
+    (tmp_path / "ok.png").write_bytes(png(3, 2, zlib.compress(good_raw)))
+    assert hostapi.load_image(str(tmp_path / "ok.png")).tobytes() == img.tobytes()
