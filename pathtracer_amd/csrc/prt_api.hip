@@ -47,7 +47,7 @@ static hipError_t scratch_for_device(int device)
     return hipSuccess;
 }
 
-static constexpr uint32_t kStatWords    = 32;
+static constexpr uint32_t kStatWords    = 48;  // [0..28]: prt_kernels.hpp FrameView::stats; [36..42]: PRT_SHADE_STAMPS builds
 static constexpr uint32_t kCounterWords = 256;
 // UI cap is 10 (vkContext.cpp:266). The shader indexes scrambleArray[16] with 1 + bounce (pathRT.rgen:635-642, :703) and
 // takes Sobol dimensions 4 + 4*bounce .. +3 of the 64 kept here: both are defined up to 14 bounces.
@@ -58,8 +58,10 @@ static constexpr int      kMaxPipes     = 8;
 struct Pipe
 {
     hipStream_t stream = nullptr;
-    float4 *    rayO = nullptr, *rayD = nullptr, *hit = nullptr, *thr = nullptr, *shD = nullptr,
-           *eiVis = nullptr, *contrib = nullptr;
+    // path state by queue slot, two generations (FrameView::gen); shadow rays by shadow-queue slot
+    float4 *   rayO[2] = {nullptr, nullptr}, *rayD[2] = {nullptr, nullptr}, *hit[2] = {nullptr, nullptr},
+           *thr[2] = {nullptr, nullptr};
+    float4 *   shO = nullptr, *shD = nullptr, *eiVis = nullptr, *contrib = nullptr;
     float2*    aaOff  = nullptr;
     uint32_t*  hitIds = nullptr;
     uint8_t *  dead = nullptr, *nvert = nullptr;
@@ -184,7 +186,11 @@ static void pipe_free(Pipe& p)
 }
 static void pipe_free_buffers(Pipe& p)
 {
-    dfree(p.rayO); dfree(p.rayD); dfree(p.hit); dfree(p.thr); dfree(p.shD); dfree(p.eiVis);
+    for(int g = 0; g < 2; ++g)
+    {
+        dfree(p.rayO[g]); dfree(p.rayD[g]); dfree(p.hit[g]); dfree(p.thr[g]);
+    }
+    dfree(p.shO); dfree(p.shD); dfree(p.eiVis);
     dfree(p.contrib); dfree(p.aaOff); dfree(p.hitIds); dfree(p.dead); dfree(p.nvert); dfree(p.q[0]); dfree(p.q[1]);
     dfree(p.qShadow);
     p.contribCap = 0;
@@ -204,10 +210,14 @@ static hipError_t pipe_alloc(Pipe& p, size_t n)
     }
     if(e != hipSuccess || n <= p.cap) return e;
     pipe_free_buffers(p);
-    if(e == hipSuccess) e = dalloc(p.rayO, n);
-    if(e == hipSuccess) e = dalloc(p.rayD, n);
-    if(e == hipSuccess) e = dalloc(p.hit, n);
-    if(e == hipSuccess) e = dalloc(p.thr, n);
+    for(int g = 0; g < 2; ++g)
+    {
+        if(e == hipSuccess) e = dalloc(p.rayO[g], n);
+        if(e == hipSuccess) e = dalloc(p.rayD[g], n);
+        if(e == hipSuccess) e = dalloc(p.hit[g], n);
+        if(e == hipSuccess) e = dalloc(p.thr[g], n);
+    }
+    if(e == hipSuccess) e = dalloc(p.shO, n);
     if(e == hipSuccess) e = dalloc(p.shD, n);
     if(e == hipSuccess) e = dalloc(p.eiVis, n);
     if(e == hipSuccess) e = dalloc(p.aaOff, n);
@@ -836,12 +846,11 @@ static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& 
     f.npixImg = c->npix;
     f.iterStride = iterStride;
     f.accum   = c->accum;
-    f.rayO    = p.rayO;
-    f.rayD    = p.rayD;
-    f.hit     = p.hit;
-    f.thr     = p.thr;
+    for(int g = 0; g < 2; ++g) f.gen[g] = PathGen{p.rayO[g], p.rayD[g], p.hit[g], p.thr[g], p.q[g]};
+    f.shO     = p.shO;
     f.shD     = p.shD;
     f.eiVis   = p.eiVis;
+    f.shPx    = p.qShadow;
     f.contrib = p.contrib;
     f.aaOff   = p.aaOff;
     f.hitIds  = p.hitIds;
@@ -851,7 +860,7 @@ static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& 
 }
 
 static void launch_extend(prt_context* c, hipStream_t st, const SceneView& sc, const FrameView& f, uint32_t grid,
-                          const uint32_t* q, const uint32_t* n, uint32_t* work, uint32_t primary)
+                          uint32_t q /* generation of path state */, const uint32_t* n, uint32_t* work, uint32_t primary)
 {
     ProfScope ps(c, PRT_K_EXTEND, st);
     if(c->profLevel >= 2)
@@ -876,7 +885,7 @@ static int render_ao(prt_context* c)
         ProfScope ps(c, PRT_K_GENERATE, st);
         hipLaunchKernelGGL(k_ao_generate, dim3(gridPix), dim3(256), 0, st, f, c->ubo, c->flags);
     }
-    launch_extend(c, st, sc, f, c->gridExtend, nullptr, nullptr, p.counters + 0, 1u);
+    launch_extend(c, st, sc, f, c->gridExtend, 0u, nullptr, p.counters + 0, 1u);
     {
         ProfScope ps(c, PRT_K_AO_SHADE, st);
         hipLaunchKernelGGL(k_ao_shade, dim3(c->gridAo), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo, c->flags,
@@ -942,28 +951,24 @@ static int render_path_pass(prt_context* c, int pi, int aa, uint32_t nsub = 1, u
     }
     for(int b = 0; b <= B; ++b)
     {
-        const uint32_t* qIn  = b == 0 ? nullptr : p.q[b & 1];
-        const uint32_t* nIn  = b == 0 ? nullptr : p.counters + b;
-        uint32_t*       qOut = p.q[(b + 1) & 1];
+        const uint32_t* nIn = b == 0 ? nullptr : p.counters + b;  // vertex b's paths: slots 0 .. *nIn-1 of generation b & 1
         // with fusion the extension rays of bounce b >= 1 were traced together with the shadow rays of bounce b-1
-        if(b == 0 || !c->fuse) launch_extend(c, st, sc, f, c->gridExtend, qIn, nIn, p.counters + 64 + b, b == 0 ? 1u : 0u);
+        if(b == 0 || !c->fuse) launch_extend(c, st, sc, f, c->gridExtend, (uint32_t)b, nIn, p.counters + 64 + b, b == 0 ? 1u : 0u);
         {
             ProfScope ps(c, PRT_K_SHADE, st);
-            hipLaunchKernelGGL(k_shade, dim3(gridShade), dim3(256), 0, st, sc, f, c->ubo, fl, (uint32_t)b, qIn, nIn,
-                               qOut, p.counters + b + 1, p.qShadow, p.counters + 32 + b);
+            hipLaunchKernelGGL(k_shade, dim3(gridShade), dim3(256), 0, st, sc, f, c->ubo, fl, (uint32_t)b, nIn,
+                               p.counters + b + 1, p.counters + 32 + b);
         }
         if(c->fuse && b < B)
         {
             ProfScope ps(c, PRT_K_SHADOW_EXTEND, st);
             if(c->profLevel >= 2)
                 hipLaunchKernelGGL(k_shadow_extend<true>, dim3(c->gridFused), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                                   (const uint32_t*)p.qShadow, (const uint32_t*)(p.counters + 32 + b),
-                                   p.counters + 128 + b, (uint32_t)b, (const uint32_t*)qOut,
+                                   (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
                                    (const uint32_t*)(p.counters + b + 1), p.counters + 64 + b + 1, trace_tune());
             else
                 hipLaunchKernelGGL(k_shadow_extend<false>, dim3(c->gridFused), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                                   (const uint32_t*)p.qShadow, (const uint32_t*)(p.counters + 32 + b),
-                                   p.counters + 128 + b, (uint32_t)b, (const uint32_t*)qOut,
+                                   (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
                                    (const uint32_t*)(p.counters + b + 1), p.counters + 64 + b + 1, trace_tune());
         }
         else
@@ -971,11 +976,11 @@ static int render_path_pass(prt_context* c, int pi, int aa, uint32_t nsub = 1, u
             ProfScope ps(c, PRT_K_SHADOW, st);
             if(c->profLevel >= 2)
                 hipLaunchKernelGGL(k_shadow<true>, dim3(c->gridShadow), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                                   (const uint32_t*)p.qShadow, (const uint32_t*)(p.counters + 32 + b),
+                                   (const uint32_t*)(p.counters + 32 + b),
                                    p.counters + 128 + b, (uint32_t)b, trace_tune());
             else
                 hipLaunchKernelGGL(k_shadow<false>, dim3(c->gridShadow), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                                   (const uint32_t*)p.qShadow, (const uint32_t*)(p.counters + 32 + b),
+                                   (const uint32_t*)(p.counters + 32 + b),
                                    p.counters + 128 + b, (uint32_t)b, trace_tune());
         }
     }
@@ -1362,6 +1367,16 @@ int prt_read_bvh(prt_context* c, prt_bvh_node* nodes, uint32_t* order)
         HIPCHK(c, e);
     }
     if(order) HIPCHK(c, hipMemcpy(order, c->dOrder, (size_t)c->ntri * 4, hipMemcpyDeviceToHost));
+    return PRT_OK;
+}
+
+// measurement builds (-DPRT_SHADE_STAMPS): the raw statistics words
+int prt_debug_read_stats(prt_context* c, unsigned long long* out48)
+{
+    if(!c || !out48) return PRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, sync_all(c));
+    HIPCHK(c, hipMemcpy(out48, c->stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PRT_OK;
 }
 

@@ -43,6 +43,15 @@ struct SceneView
     BvhView             bvh;
 };
 
+struct PathGen
+{
+    float4*   rayO;  // Ro.xyz, tmin
+    float4*   rayD;  // Rd.xyz, tmax
+    float4*   hit;   // prim bits, u, v, t
+    float4*   thr;   // throughput.xyz, p
+    uint32_t* px;    // pixel of the pass
+};
+
 struct FrameView
 {
     uint32_t  w, h;
@@ -50,13 +59,16 @@ struct FrameView
                            // of the pass is image pixel k % npixImg of iteration ubo.iteration + (k / npixImg) * iterStride
     uint32_t  npixImg, iterStride;
     float4*   accum;
-    float4*   rayO;   // Ro.xyz, tmin
-    float4*   rayD;   // Rd.xyz, tmax
-    float4*   hit;    // prim bits, u, v, t
-    float4*   thr;    // throughput.xyz, p
-    // hitPoint.xyz, color.w
+    // Path state lives at QUEUE SLOTS, not at pixels: the paths that survive vertex b are written, compacted, into
+    // generation (b+1)&1 by k_shade(b), traced there by k_shadow_extend(b) and read back by k_shade(b+1) — every
+    // access of a wave is a run of consecutive records. Generation 0 at vertex 0 is the identity (slot == pixel of
+    // the pass, `px` unused).
+    PathGen   gen[2];
+    // shadow rays of the current vertex, by slot of the shadow queue
+    float4*   shO;    // hitPoint.xyz, tmin
     float4*   shD;    // vLight.xyz, -
     float4*   eiVis;  // radiance term if the light sample is visible (w = color.w)
+    uint32_t* shPx;   // pixel of the pass the term belongs to
     float4*   contrib;  // [vertex][npix]: radiance term of every path vertex of this pass (w = color.w)
     float2*   aaOff;  // rayOffset (only read when numAArays != 1)
     uint32_t* hitIds; // primary-ray primitive id per pixel
@@ -103,6 +115,49 @@ PRT_DEV uint32_t block_push(bool pred, uint32_t* counter, uint32_t* lds /*[8]*/)
     const uint32_t base = lds[4 + wid];
     __syncthreads();
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// block_push in two halves, so that the round trip of the counter's atomic (it executes at the memory side) runs
+// beside the work between them. begin: every wave leaves its count in lds[0..3], thread 0 issues the atomic and KEEPS
+// the returned base in a register (no wait here: the wait lands where the value is first used, in push_end).
+// end: thread 0 turns the base into per-wave bases (lds[4..7]); every thread gets its slot. `lds` = 8 words that no
+// other push uses between the two calls.
+struct PushTicket
+{
+    unsigned long long mask;
+    uint32_t           base;  // thread 0 only
+};
+PRT_DEV PushTicket block_push_begin(bool pred, uint32_t* counter, uint32_t* lds /*[8]*/)
+{
+    PushTicket t;
+    t.mask = __ballot(pred);
+    t.base = 0;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if(lane == 0) lds[wid] = (uint32_t)__popcll(t.mask);
+    __syncthreads();
+    if(threadIdx.x == 0)
+    {
+        const uint32_t tot = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+        if(tot) t.base = atomicAdd(counter, tot);
+    }
+    return t;
+}
+// thread 0's part of the second half (call for every pending ticket, then ONE __syncthreads, then block_push_slot)
+PRT_DEV void block_push_publish(const PushTicket& t, uint32_t* lds)
+{
+    if(threadIdx.x == 0)
+    {
+        const uint32_t n0 = lds[0], n1 = lds[1], n2 = lds[2];
+        lds[4] = t.base;
+        lds[5] = t.base + n0;
+        lds[6] = t.base + n0 + n1;
+        lds[7] = t.base + n0 + n1 + n2;
+    }
+}
+PRT_DEV uint32_t block_push_slot(const PushTicket& t, const uint32_t* lds)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    return lds[4 + wid] + (uint32_t)__popcll(t.mask & ((1ull << lane) - 1ull));
 }
 
 PRT_DEV uint32_t wave_fetch(uint32_t* workCtr, uint32_t n)
@@ -174,8 +229,8 @@ __global__ void __launch_bounds__(256) k_generate(SceneView sc, FrameView f, con
     }
     else if(f.dead[px])
     {
-        f.rayO[px] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-        f.rayD[px] = make_float4(0.0f, 0.0f, 1.0f, -1.0f);  // empty interval: traces as a miss
+        f.gen[0].rayO[px] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        f.gen[0].rayD[px] = make_float4(0.0f, 0.0f, 1.0f, -1.0f);  // empty interval: traces as a miss
         return;
     }
     const uint32_t sub = px / f.npixImg, ip = px - sub * f.npixImg;  // iteration of the batch, image pixel
@@ -200,9 +255,9 @@ __global__ void __launch_bounds__(256) k_generate(SceneView sc, FrameView f, con
         primary_ray(ubo->projViewInverse, x, y, f.w, f.h, off.x, off.y, Ro, Rd);
         f.aaOff[px] = make_float2(off.x, off.y);
     }
-    st_nt(f.rayO + px, make_float4(Ro.x, Ro.y, Ro.z, 0.000001f));
-    st_nt(f.rayD + px, make_float4(Rd.x, Rd.y, Rd.z, 1.0f));
-    st_nt(f.thr + px, make_float4(1.0f, 1.0f, 1.0f, 1.0f));
+    st_nt(f.gen[0].rayO + px, make_float4(Ro.x, Ro.y, Ro.z, 0.000001f));
+    st_nt(f.gen[0].rayD + px, make_float4(Rd.x, Rd.y, Rd.z, 1.0f));
+    st_nt(f.gen[0].thr + px, make_float4(1.0f, 1.0f, 1.0f, 1.0f));
 }
 
 // AO.rgen:185-205 — pixel-centre primary ray, tmin 1e-5
@@ -214,33 +269,36 @@ __global__ void __launch_bounds__(256) k_ao_generate(FrameView f, const prt_unif
     if((flags & PRT_FLAG_LITERAL) && !(ubo->iteration > 1u)) f.accum[px] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     f3 Ro, Rd;
     primary_ray(ubo->projViewInverse, px % f.w, px / f.w, f.w, f.h, 0.5f, 0.5f, Ro, Rd);
-    f.rayO[px] = make_float4(Ro.x, Ro.y, Ro.z, 0.00001f);
-    f.rayD[px] = make_float4(Rd.x, Rd.y, Rd.z, 1.0f);
+    f.gen[0].rayO[px] = make_float4(Ro.x, Ro.y, Ro.z, 0.00001f);
+    f.gen[0].rayD[px] = make_float4(Rd.x, Rd.y, Rd.z, 1.0f);
 }
 
 // ---------------------------------------------------------------------------------------------
-// extend — closest hit for every queued ray. queue == nullptr: identity (all pixels).
+// extend — closest hit for every ray of one generation of path state (slots 0 .. count-1)
 // ---------------------------------------------------------------------------------------------
 struct ExtendIO
 {
-    const FrameView& f;
-    const uint32_t*  queue;
-    uint32_t         primary;
+    struct
+    {
+        const float4 *rayO, *rayD;
+        float4*       hit;
+    } g;
+    uint32_t* hitIds;  // primary rays only (slot == pixel), else nullptr
+    PRT_DEV ExtendIO(const PathGen& p, uint32_t* ids) : g{p.rayO, p.rayD, p.hit}, hitIds(ids) {}
     PRT_DEV bool load(uint32_t i, f3& o, float& tmin, f3& d, float& tmax, uint32_t& tag) const
     {
-        const uint32_t px = queue ? ld_nt(queue + i) : i;
-        const float4   oq = ld_nt(f.rayO + px), dq = ld_nt(f.rayD + px);
+        const float4 oq = ld_nt(g.rayO + i), dq = ld_nt(g.rayD + i);
         o    = mk3(oq.x, oq.y, oq.z);
         tmin = oq.w;
         d    = mk3(dq.x, dq.y, dq.z);
         tmax = dq.w;
-        tag  = px;
+        tag  = i;
         return !(dq.w < 0.0f);  // placeholder rays of pixels that already returned are not counted
     }
-    PRT_DEV void store(uint32_t px, const Hit& h) const
+    PRT_DEV void store(uint32_t i, const Hit& h) const
     {
-        st_nt(f.hit + px, make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t));
-        if(primary) st_nt(f.hitIds + px, h.prim);
+        st_nt(g.hit + i, make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t));
+        if(hitIds) st_nt(hitIds + i, h.prim);
     }
 };
 
@@ -248,7 +306,7 @@ struct ExtendIO
 #define PRT_TRACE_ATTR
 #endif
 template <bool INSTR>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_extend(SceneView sc, FrameView f, const uint32_t* __restrict__ queue,
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_extend(SceneView sc, FrameView f, uint32_t generation,
                                                             const uint32_t* __restrict__ countPtr,
                                                             uint32_t* workCtr, uint32_t primary, TraceTune tune)
 {
@@ -256,7 +314,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) 
     const uint32_t      count = countPtr ? *countPtr : f.npix;
     uint32_t            nskip = 0;
     TraceCount          tc    = {};
-    ExtendIO            io{f, queue, primary};
+    ExtendIO            io(f.gen[generation & 1u], primary ? f.hitIds : nullptr);
     trace_stream<false, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nskip, tc);
     flush_counts<INSTR>(f, count, nskip, tc, 0);
 }
@@ -317,11 +375,10 @@ __global__ void __launch_bounds__(256) k_gather_shading(const prt_vertex* __rest
 #define PRT_SHADE_WAVES 4  // 128 VGPRs, no scratch; 5 or 6 spill and are slower, 2-3 leave the compiler 132 VGPRs = 3 waves per SIMD
 #endif
 __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,
-                                               uint32_t bounce, const uint32_t* __restrict__ queueIn,
-                                               const uint32_t* __restrict__ countIn, uint32_t* __restrict__ queueNext,
-                                               uint32_t* countNext, uint32_t* __restrict__ queueShadow,
-                                               uint32_t* countShadow)
+                                               uint32_t bounce, const uint32_t* __restrict__ countIn,
+                                               uint32_t* countNext, uint32_t* countShadow)
 {
+    const PathGen gin = f.gen[bounce & 1u], gout = f.gen[(bounce + 1u) & 1u];
     const prt_uniforms* ubo = &ubo_;
     // Sobol byte tables of this vertex's dimensions (4 + 4*bounce .. +3) and of the roulette dimension
     __shared__ uint32_t sobT[5 * 1024];
@@ -336,24 +393,55 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
         __syncthreads();
     }
     const uint32_t count      = countIn ? *countIn : f.npix;
-    __shared__ uint32_t pushLds[8];
+    __shared__ uint32_t pushLds[2][2][8];  // [trip parity][shadow | next]: a trip's slots are read while the next trip counts
     const bool     literal    = (flags & PRT_FLAG_LITERAL) != 0;
     const bool     rr         = (flags & PRT_FLAG_RUSSIAN_ROULETTE) != 0;
     const int      maxBounces = ubo->numIndirectBounces;
     const int      numAA      = ubo->numAArays;
 
-    for(uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u)  // block-uniform trip count
+#ifdef PRT_SHADE_STAMPS  // measurement builds only: where a trip's cycles go (sums over waves, lane 0) -> stats[36..41]
+    unsigned long long stampT[6] = {0, 0, 0, 0, 0, 0};
+#define PRT_STAMP(k)                                                     \
+    {                                                                    \
+        __builtin_amdgcn_s_waitcnt(0);                                   \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+        stampT[k] += now_ - stampMark;                                   \
+        stampMark = now_;                                                \
+    }
+#else
+#define PRT_STAMP(k)
+#endif
+    uint32_t parity = 0;
+    for(uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u, parity ^= 1u)  // block-uniform trip count
     {
+#ifdef PRT_SHADE_STAMPS
+        unsigned long long stampMark = __builtin_amdgcn_s_memtime();
+#endif
         const uint32_t i       = base + threadIdx.x;
         bool           shadowQ = false, nextQ = false;
         uint32_t       px      = 0;
+        // every vertex that is shaded sends a shadow ray: its queue slot is reserved now, and the atomic's round trip
+        // runs beside the shading
+        float4 hq0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if(i < count)
         {
-            px                 = queueIn ? ld_nt(queueIn + i) : i;
-            // everything that depends on px only is requested together (one round trip, not one per use)
-            const float4   hq  = ld_nt(f.hit + px);
-            const float4   rd4 = ld_nt(f.rayD + px);
-            const float4   th4 = ld_nt(f.thr + px);
+            px  = bounce ? ld_nt(gin.px + i) : i;
+            hq0 = ld_nt(gin.hit + i);
+            shadowQ = (uint32_t)__float_as_int(hq0.x) != 0xffffffffu && !((bounce == 0) && f.dead[px]);
+        }
+        // what the vertex leaves behind is stored after the compactions, at the slots they hand out
+        float4 oOrg = hq0, oShD = hq0, oEiV = hq0, oDir = hq0, oThr = hq0;
+        float4 rd4 = hq0, th4 = hq0;
+        if(i < count)
+        {
+            rd4 = ld_nt(gin.rayD + i);
+            th4 = ld_nt(gin.thr + i);
+        }
+        const PushTicket tShadow = block_push_begin(shadowQ, countShadow, pushLds[parity][0]);
+        PRT_STAMP(0)  // path state of the slot, the shadow queue's ticket
+        if(i < count)
+        {
+            const float4   hq  = hq0;
             const uint32_t nv0 = literal ? (uint32_t)(f.nvert[px] & 0x80) : 0u;  // set by k_generate in literal mode only
             const uint32_t primitiveID = (uint32_t)__float_as_int(hq.x);
             const bool     isDead      = (bounce == 0) && f.dead[px];
@@ -393,6 +481,7 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                 const uint32_t      mi  = (tri.mat >= 0 && (uint32_t)tri.mat < sc.nmats) ? (uint32_t)tri.mat : 0u;
                 const prt_material& mat = sc.mats[mi];
 
+                PRT_STAMP(1)  // shading triangle (+ whatever else the compiler hoisted)
                 f3 sNormal = normalize3((v0.normal * bary.x + v1.normal * bary.y) + v2.normal * bary.z);
                 if(dot3(sNormal, Rd) > 0.0f) sNormal = -sNormal;
                 const f3 gNormal  = sNormal;
@@ -531,6 +620,7 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                     colorw              = colorw / weight;
                 }
 
+                PRT_STAMP(2)  // material, textures, light sample, BSDF sample
                 // accumulate — :939-942; the shadow kernel picks one of the two, k_resolve adds it to E
                 const f3 em  = mk3(mat.emission[0], mat.emission[1], mat.emission[2]) * ubo->lightOtherE;
                 const f3 tc  = throughput * color;
@@ -539,12 +629,11 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                 EiV          = EiV + em;
                 EiV          = EiV * tc;
                 // origin of the shadow ray and of the extension ray alike (:805, :922), tmin 1e-6 for both
-                st_nt(f.rayO + px, make_float4(hitPoint.x, hitPoint.y, hitPoint.z, 0.000001f));
-                st_nt(f.shD + px, make_float4(vLight.x, vLight.y, vLight.z, 0.0f));
-                st_nt(f.eiVis + px, make_float4(EiV.x, EiV.y, EiV.z, colorw));
+                oOrg = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, 0.000001f);
+                oShD = make_float4(vLight.x, vLight.y, vLight.z, 0.0f);
+                oEiV = make_float4(EiV.x, EiV.y, EiV.z, colorw);
                 st_nt(f.contrib + ((size_t)bounce * f.npix + px), make_float4(EiO.x, EiO.y, EiO.z, colorw));
                 f.nvert[px]  = (uint8_t)(nv0 | (bounce + 1u));
-                shadowQ      = true;
 
                 // termination — :944-961
                 bool alive = true;
@@ -569,17 +658,42 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                 }
                 if(alive)
                 {
-                    st_nt(f.rayD + px, make_float4(Rn.x, Rn.y, Rn.z, 1.0f));
-                    st_nt(f.thr + px, make_float4(throughput.x, throughput.y, throughput.z, p));
-                    nextQ      = true;
+                    oDir  = make_float4(Rn.x, Rn.y, Rn.z, 1.0f);
+                    oThr  = make_float4(throughput.x, throughput.y, throughput.z, p);
+                    nextQ = true;
                 }
             }
         }
-        const uint32_t si = block_push(shadowQ, countShadow, pushLds);
-        if(shadowQ) st_nt(queueShadow + si, px);
-        const uint32_t ni = block_push(nextQ, countNext, pushLds);
-        if(nextQ) st_nt(queueNext + ni, px);
+        PRT_STAMP(3)  // stores, termination
+        const PushTicket tNext = block_push_begin(nextQ, countNext, pushLds[parity][1]);
+        block_push_publish(tShadow, pushLds[parity][0]);
+        block_push_publish(tNext, pushLds[parity][1]);
+        __syncthreads();
+        PRT_STAMP(4)  // compaction
+        if(shadowQ)
+        {
+            const uint32_t s = block_push_slot(tShadow, pushLds[parity][0]);
+            st_nt(f.shPx + s, px);
+            st_nt(f.shO + s, oOrg);
+            st_nt(f.shD + s, oShD);
+            st_nt(f.eiVis + s, oEiV);
+        }
+        if(nextQ)
+        {
+            const uint32_t s = block_push_slot(tNext, pushLds[parity][1]);
+            st_nt(gout.px + s, px);
+            st_nt(gout.rayO + s, oOrg);
+            st_nt(gout.rayD + s, oDir);
+            st_nt(gout.thr + s, oThr);
+        }
+        PRT_STAMP(5)  // stores by slot
     }
+#ifdef PRT_SHADE_STAMPS
+    if((threadIdx.x & 63) == 0)
+        for(int k = 0; k < 6; ++k) atomicAdd(f.stats + 36 + k, stampT[k]);
+    if(threadIdx.x == 0) atomicAdd(f.stats + 42, (unsigned long long)((count + 255u) / 256u > blockIdx.x ? ((count + 255u) / 256u - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u));
+#endif
+#undef PRT_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -588,28 +702,25 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
 struct ShadowIO
 {
     const FrameView& f;
-    const uint32_t*  queue;
     float4*          term;  // contrib + bounce * npix
     PRT_DEV bool load(uint32_t i, f3& o, float& tmin, f3& d, float& tmax, uint32_t& tag) const
     {
-        const uint32_t px = ld_nt(queue + i);
-        const float4   oq = ld_nt(f.rayO + px), dq = ld_nt(f.shD + px);
+        const float4 oq = ld_nt(f.shO + i), dq = ld_nt(f.shD + i);
         o    = mk3(oq.x, oq.y, oq.z);
         tmin = 0.000001f;
         d    = mk3(dq.x, dq.y, dq.z);
         tmax = 1.0f;
-        tag  = px;
+        tag  = i;
         return true;
     }
-    PRT_DEV void store(uint32_t px, const Hit& h) const
+    PRT_DEV void store(uint32_t i, const Hit& h) const
     {
-        if(h.prim == 0xffffffffu) st_nt(term + px, ld_nt(f.eiVis + px));  // visible: Ei_occ -> Ei_vis
+        if(h.prim == 0xffffffffu) st_nt(term + ld_nt(f.shPx + i), ld_nt(f.eiVis + i));  // visible: Ei_occ -> Ei_vis
     }
 };
 
 template <bool INSTR>
 __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow(SceneView sc, FrameView f,
-                                                            const uint32_t* __restrict__ queue,
                                                             const uint32_t* __restrict__ countPtr, uint32_t* workCtr,
                                                             uint32_t bounce, TraceTune tune)
 {
@@ -617,7 +728,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) 
     const uint32_t      count = *countPtr;
     uint32_t            nskip = 0;
     TraceCount          tc    = {};
-    ShadowIO            io{f, queue, f.contrib + (size_t)bounce * f.npix};
+    ShadowIO            io{f, f.contrib + (size_t)bounce * f.npix};
     trace_stream<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nskip, tc);
     flush_counts<INSTR>(f, count, nskip, tc, 1);
 }
@@ -628,16 +739,15 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) 
 // an empty GPU — one launch tail per bounce instead of two.
 template <bool INSTR>
 __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow_extend(
-    SceneView sc, FrameView f, const uint32_t* __restrict__ shQueue, const uint32_t* __restrict__ shCountPtr,
-    uint32_t* shWork, uint32_t bounce, const uint32_t* __restrict__ exQueue, const uint32_t* __restrict__ exCountPtr,
-    uint32_t* exWork, TraceTune tune)
+    SceneView sc, FrameView f, const uint32_t* __restrict__ shCountPtr, uint32_t* shWork, uint32_t bounce,
+    const uint32_t* __restrict__ exCountPtr, uint32_t* exWork, TraceTune tune)
 {
     __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
     {
         const uint32_t count = *exCountPtr;
         uint32_t       nskip = 0;
         TraceCount     tc    = {};
-        ExtendIO       io{f, exQueue, 0u};
+        ExtendIO       io(f.gen[(bounce + 1u) & 1u], nullptr);
         trace_stream<false, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, exWork, tune, io, nskip, tc);
         flush_counts<INSTR>(f, count, nskip, tc, 0);
         if(blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(f.stats + 6, (unsigned long long)count);
@@ -646,7 +756,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) 
         const uint32_t count = *shCountPtr;
         uint32_t       nskip = 0;
         TraceCount     tc    = {};
-        ShadowIO       io{f, shQueue, f.contrib + (size_t)bounce * f.npix};
+        ShadowIO       io{f, f.contrib + (size_t)bounce * f.npix};
         trace_stream<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, shWork, tune, io, nskip, tc);
         flush_counts<INSTR>(f, count, nskip, tc, 1);
         if(blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(f.stats + 7, (unsigned long long)count);
@@ -712,7 +822,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
         const uint32_t px = base0 + sub * 64u + lane;
         if(px < count)
         {
-            const float4   hq   = f.hit[px];
+            const float4   hq   = f.gen[0].hit[px];
             const uint32_t prim = (uint32_t)__float_as_int(hq.x);
             const float4   E    = f.accum[px];
             if(prim == 0xffffffffu)
@@ -728,7 +838,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
                 const TriU     tri = load_tri(sc.stri, prim);
                 const VertexU &v0 = tri.v0, &v1 = tri.v1, &v2 = tri.v2;
                 const f3      bary = mk3(1.0f - hq.y - hq.z, hq.y, hq.z);
-                const float4  rd4  = f.rayD[px];
+                const float4  rd4  = f.gen[0].rayD[px];
                 f3 normal = normalize3((v0.normal * bary.x + v1.normal * bary.y) + v2.normal * bary.z);
                 if(dot3(normal, mk3(rd4.x, rd4.y, rd4.z)) > 0.0f) normal = normal * -1.0f;
                 const m3 onb      = form_basis(normal);
