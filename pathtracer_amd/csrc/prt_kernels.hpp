@@ -411,40 +411,59 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
 #else
 #define PRT_STAMP(k)
 #endif
-    uint32_t parity = 0;
+    // The loop is software-pipelined by hand: the path state of the NEXT trip is requested before this trip's results
+    // are stored. vmcnt counts loads and stores in one in-order queue, so a load that is issued after the stores cannot
+    // be waited for without waiting for every store's acknowledgement as well (thousands of cycles for the scattered
+    // ones); requested before them, the state is there when the next trip starts.
+    struct SlotState
+    {
+        uint32_t px;
+        float4   hit, rayD, thr;
+        bool     dead;
+    };
+    auto load_state = [&](uint32_t i) {
+        SlotState st;
+        st.px   = 0;
+        st.hit  = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        st.rayD = st.hit;
+        st.thr  = st.hit;
+        st.dead = false;
+        if(i < count)
+        {
+            st.px   = bounce ? ld_nt(gin.px + i) : i;
+            st.hit  = ld_nt(gin.hit + i);
+            st.rayD = ld_nt(gin.rayD + i);
+            st.thr  = ld_nt(gin.thr + i);
+            st.dead = (bounce == 0) && f.dead[i];  // bounce 0: slot == pixel
+        }
+        return st;
+    };
+    SlotState nx     = load_state(blockIdx.x * 256u + threadIdx.x);
+    uint32_t  parity = 0;
     for(uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u, parity ^= 1u)  // block-uniform trip count
     {
 #ifdef PRT_SHADE_STAMPS
         unsigned long long stampMark = __builtin_amdgcn_s_memtime();
 #endif
-        const uint32_t i       = base + threadIdx.x;
-        bool           shadowQ = false, nextQ = false;
-        uint32_t       px      = 0;
+        const uint32_t  i       = base + threadIdx.x;
+        const SlotState in      = nx;
+        const uint32_t  px      = in.px;
+        const float4    hq0     = in.hit, rd4 = in.rayD, th4 = in.thr;
+        bool            nextQ   = false, endQ = false;
         // every vertex that is shaded sends a shadow ray: its queue slot is reserved now, and the atomic's round trip
         // runs beside the shading
-        float4 hq0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if(i < count)
-        {
-            px  = bounce ? ld_nt(gin.px + i) : i;
-            hq0 = ld_nt(gin.hit + i);
-            shadowQ = (uint32_t)__float_as_int(hq0.x) != 0xffffffffu && !((bounce == 0) && f.dead[px]);
-        }
+        const bool shadowQ = i < count && (uint32_t)__float_as_int(hq0.x) != 0xffffffffu && !in.dead;
         // what the vertex leaves behind is stored after the compactions, at the slots they hand out
-        float4 oOrg = hq0, oShD = hq0, oEiV = hq0, oDir = hq0, oThr = hq0;
-        float4 rd4 = hq0, th4 = hq0;
-        if(i < count)
-        {
-            rd4 = ld_nt(gin.rayD + i);
-            th4 = ld_nt(gin.thr + i);
-        }
+        float4 oOrg = hq0, oShD = hq0, oEiV = hq0, oEiO = hq0, oDir = hq0, oThr = hq0;
         const PushTicket tShadow = block_push_begin(shadowQ, countShadow, pushLds[parity][0]);
         PRT_STAMP(0)  // path state of the slot, the shadow queue's ticket
         if(i < count)
         {
             const float4   hq  = hq0;
-            const uint32_t nv0 = literal ? (uint32_t)(f.nvert[px] & 0x80) : 0u;  // set by k_generate in literal mode only
+            // nvert[px] is written once per path, where the path ends: at the vertex that is not continued, or by the
+            // miss that follows the last vertex. Bit 0x80 (set by k_generate in literal mode only) is kept.
             const uint32_t primitiveID = (uint32_t)__float_as_int(hq.x);
-            const bool     isDead      = (bounce == 0) && f.dead[px];
+            const bool     isDead      = in.dead;
             if(primitiveID == 0xffffffffu || isDead)
             {
                 if(bounce == 0 && !isDead)
@@ -455,9 +474,11 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                     const float    u = ((float)x + 0.5f) / (float)f.w, v = ((float)y + 0.5f) / (float)f.h;
                     // literal: the miss colour replaces E; default: it is one more term of the sum
                     f.contrib[px] = make_float4(u, v, 0.4f, 1.0f);
-                    f.nvert[px]   = (uint8_t)(nv0 | (literal ? 0x41u : 0x01u));
+                    f.nvert[px]   = (uint8_t)((literal ? (f.nvert[px] & 0x80u) | 0x41u : 0x01u));
                     f.dead[px]    = 1;
                 }
+                else if(bounce != 0)
+                    endQ = true;  // `bounce` terms stored
             }
             else
             {
@@ -632,8 +653,7 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                 oOrg = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, 0.000001f);
                 oShD = make_float4(vLight.x, vLight.y, vLight.z, 0.0f);
                 oEiV = make_float4(EiV.x, EiV.y, EiV.z, colorw);
-                st_nt(f.contrib + ((size_t)bounce * f.npix + px), make_float4(EiO.x, EiO.y, EiO.z, colorw));
-                f.nvert[px]  = (uint8_t)(nv0 | (bounce + 1u));
+                oEiO = make_float4(EiO.x, EiO.y, EiO.z, colorw);
 
                 // termination — :944-961
                 bool alive = true;
@@ -656,7 +676,9 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                     else
                         throughput = throughput / mk3(q);
                 }
-                if(alive)
+                if(!alive)
+                    endQ = true;
+                else
                 {
                     oDir  = make_float4(Rn.x, Rn.y, Rn.z, 1.0f);
                     oThr  = make_float4(throughput.x, throughput.y, throughput.z, p);
@@ -666,13 +688,17 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
         }
         PRT_STAMP(3)  // stores, termination
         const PushTicket tNext = block_push_begin(nextQ, countNext, pushLds[parity][1]);
+        nx = load_state(i + gridDim.x * 256u);
         block_push_publish(tShadow, pushLds[parity][0]);
         block_push_publish(tNext, pushLds[parity][1]);
         __syncthreads();
         PRT_STAMP(4)  // compaction
+        if(endQ)  // the path ends here: terms stored = vertices shaded (this one included when it was a hit)
+            f.nvert[px] = (uint8_t)((literal ? (uint32_t)(f.nvert[px] & 0x80u) : 0u) | (bounce + (shadowQ ? 1u : 0u)));
         if(shadowQ)
         {
             const uint32_t s = block_push_slot(tShadow, pushLds[parity][0]);
+            st_nt(f.contrib + ((size_t)bounce * f.npix + px), oEiO);
             st_nt(f.shPx + s, px);
             st_nt(f.shO + s, oOrg);
             st_nt(f.shD + s, oShD);
