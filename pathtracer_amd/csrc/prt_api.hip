@@ -261,7 +261,7 @@ static void prof_collect(prt_context* c);
 static TraceTune trace_tune()
 {
     static TraceTune t = [] {
-        TraceTune v{16u, 24u, 8u, 0u};
+        TraceTune v{16u, 28u, 16u, 0u};  // tools/tune_sweep.sh on the bench workload
         if(const char* e = getenv("PRT_TUNE"))
         {
             unsigned a = v.refillMin, b = v.stallMax, d = v.leafMin;
