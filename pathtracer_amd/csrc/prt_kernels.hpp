@@ -297,7 +297,7 @@ struct ExtendIO
     }
     PRT_DEV void store(uint32_t i, const Hit& h) const
     {
-        st_nt(g.hit + i, make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t));
+        st_res(g.hit + i, make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t));
         if(hitIds) st_nt(hitIds + i, h.prim);
     }
 };
@@ -741,7 +741,7 @@ struct ShadowIO
     }
     PRT_DEV void store(uint32_t i, const Hit& h) const
     {
-        if(h.prim == 0xffffffffu) st_nt(term + ld_nt(f.shPx + i), ld_nt(f.eiVis + i));  // visible: Ei_occ -> Ei_vis
+        if(h.prim == 0xffffffffu) st_res(term + ld_nt(f.shPx + i), ld_nt(f.eiVis + i));  // visible: Ei_occ -> Ei_vis
     }
 };
 
