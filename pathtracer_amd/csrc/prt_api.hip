@@ -471,7 +471,7 @@ int prt_set_scene(prt_context* c, const prt_vertex* v, size_t nv, const uint32_t
     }
     HIPCHK(c, dalloc(c->dTex, ntex));
     if(ntex) HIPCHK(c, hipMemcpy(c->dTex, td.data(), ntex * sizeof(TexDesc), hipMemcpyHostToDevice));
-    HIPCHK(c, dalloc(c->dShadeTris, (size_t)c->ntri * 7));
+    HIPCHK(c, dalloc(c->dShadeTris, (size_t)c->ntri * PRT_SHADE_TRI_F4));
     hipLaunchKernelGGL(k_gather_shading, dim3(cdiv(c->ntri, 256)), dim3(256), 0, c->stream, c->dVerts, c->dIdx, c->ntri,
                        c->dShadeTris);
     HIPCHK(c, hipGetLastError());

@@ -330,6 +330,9 @@ struct VertexU
 // Shading record of one triangle, gathered once at prt_set_scene from the vertex/index buffers
 // (unpackVertex, pathRT.rgen:94-119): corner k = rows 2k, 2k+1 = (p.xyz, n.x), (n.y, n.z, t.x, t.y);
 // row 6.x = materialID of corner 1 (the shader takes the material from v1, :712).
+#ifndef PRT_SHADE_TRI_F4
+#define PRT_SHADE_TRI_F4 8  // pitch in float4: one aligned 128-byte line per triangle (7 rows used)
+#endif
 struct TriU
 {
     VertexU v0, v1, v2;
@@ -346,7 +349,7 @@ PRT_DEV VertexU unpack_corner(float4 a, float4 b)
 }
 PRT_DEV TriU load_tri(const float4* __restrict__ stri, uint32_t prim)
 {
-    const float4* q  = stri + (size_t)prim * 7;
+    const float4* q  = stri + (size_t)prim * PRT_SHADE_TRI_F4;
     const float4  q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
     TriU          t;
     t.v0  = unpack_corner(q0, q1);
@@ -361,7 +364,7 @@ __global__ void __launch_bounds__(256) k_gather_shading(const prt_vertex* __rest
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= ntri) return;
-    float4* o = stri + (size_t)i * 7;
+    float4* o = stri + (size_t)i * PRT_SHADE_TRI_F4;
     for(int k = 0; k < 3; ++k)
     {
         const prt_vertex& v = verts[idx[3 * i + k]];
