@@ -127,6 +127,22 @@ int prt_build_accel(prt_context* ctx);
 int prt_update_vertices(prt_context* ctx, const prt_vertex* vertices, size_t n_vertices);
 int prt_refit_accel(prt_context* ctx);
 
+/* Two-level scenes: the TLAS of the reference's helper takes any number of instances with transforms
+ * (TopLevelASGenerator::AddInstance, vkRT_TLAS.cpp:58-72; one bottom-level structure per geometry,
+ * vkRT_BLAS.cpp:87-109); the reference itself wires one identity instance of model 0 (vkRTX_setup.cpp:138-186), which is
+ * what a scene without this call is. `blas` = ranges of the scene's triangles (object space, materials as in the
+ * scene), `instances` = placements of them. Call between prt_set_scene and prt_build_accel; n_instances == 0 returns to
+ * the single-level scene. One BVH is built per range and shared by its instances; a top-level BVH over the instances'
+ * world boxes is walked by the same kernels, a ray enters an instance in object space (inverse transform, same t).
+ * gl_PrimitiveID as reported in hits / prt_read_hit_ids is flattened: instance i's triangles follow those of
+ * instances 0 .. i-1 (what pathtracer_amd/host/Scene.h's flattening yields). Transforms must be invertible with a
+ * condition number (row-sum norms of the 3 x 3 part) <= 1024. */
+int prt_set_instances(prt_context* ctx, const prt_blas_range* blas, size_t n_blas, const prt_instance* instances,
+                      size_t n_instances);
+/* The updateOnly path of the top level (vkRT_TLAS.cpp:178-279 with updateOnly = true): new transforms
+ * (n_instances x 16 floats, column-major) for the instances; the bottom-level structures stay. Synchronous. */
+int prt_update_instance_transforms(prt_context* ctx, const float* transforms, size_t n_instances);
+
 /* generateNewScrambles + updateScrambleValueImage — vkRTX_setup.h:38-39, vkRTX_setup.cpp:808-911.
  * Seeded, stateless per (pixel, layer) hash evaluated in the kernels (default seed 1) ... */
 int prt_set_scramble_seed(prt_context* ctx, uint32_t seed);
@@ -208,6 +224,10 @@ int prt_trace_device_noalloc(prt_context* ctx, const void* rays_dev, size_t n, i
 
 /* Inspection of the acceleration structure (nodes_out: bvh_nodes entries, order_out: one per triangle). */
 int prt_read_bvh(prt_context* ctx, prt_bvh_node* nodes_out, uint32_t* order_out);
+/* The same for bottom-level structure `blas` of a two-level scene (order: ids local to its range). nodes_out /
+ * order_out may be NULL; *n_nodes_out (optional) receives the node count. */
+int prt_read_blas_bvh(prt_context* ctx, uint32_t blas, prt_bvh_node* nodes_out, uint32_t* order_out,
+                      uint32_t* n_nodes_out);
 /* The 64 x 32 Sobol matrix words in use (sobol.h:28-33 restricted to what the path reads). */
 int prt_read_sobol(prt_context* ctx, uint32_t* words_out);
 

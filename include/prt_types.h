@@ -87,7 +87,28 @@ typedef struct prt_texture
     uint32_t       height;
 } prt_texture;
 
+/* Two-level scenes. A bottom-level structure is a range of the scene's triangles (object space); an instance places
+ * one of them in the world — TopLevelASGenerator::AddInstance(blas, transform, instanceID, hitGroupIndex),
+ * /root/reference/external/NVIDIA_RTX/vkRT_TLAS.cpp:58-72. `transform` is a column-major mat4 (glm) object -> world; as
+ * in VkGeometryInstance (vkRT_TLAS.cpp:212-214) only its 3 x 4 affine part exists: the fourth row must be (0,0,0,1).
+ * instance_id (gl_InstanceCustomIndexNV) and hit_group (SBT offset) are carried; the path's shaders read neither. */
+typedef struct prt_blas_range
+{
+    uint32_t first_triangle;
+    uint32_t n_triangles;
+} prt_blas_range;
+
+typedef struct prt_instance
+{
+    float    transform[16];
+    uint32_t blas;        /* index into the prt_blas_range array */
+    uint32_t instance_id;
+    uint32_t hit_group;
+    uint32_t pad;
+} prt_instance;
+
 #ifdef __cplusplus
+static_assert(sizeof(prt_instance) == 80, "prt_instance is 80 bytes");
 static_assert(sizeof(prt_vertex) == 48, "VertexPNTC is 48 bytes");
 static_assert(sizeof(prt_material) == 96, "Material is 96 bytes");
 static_assert(sizeof(prt_uniforms) == 464, "UniformBufferObject is 464 bytes");

@@ -133,6 +133,28 @@ struct Box
 
 }  // namespace
 
+// One acceleration structure over a range of the scene's triangles (the whole scene, or one bottom-level structure of
+// an instanced scene). Primitive ids inside it are local to the range.
+struct Geo
+{
+    uint32_t              firstTri = 0, nTri = 0;
+    std::vector<orc_node> nodes;
+    std::vector<uint32_t> order;
+    uint32_t              depth    = 0;
+    float                 sceneAbs = 0.0f;
+};
+// One instance of a bottom-level structure (vkRT_TLAS.cpp:58-72 AddInstance; VkGeometryInstance keeps the 3 x 4
+// affine part of the transform, :212-214).
+struct Inst
+{
+    float    o2w[16];   // object -> world, column-major
+    float    w2o[16];   // its inverse (glm's cofactor formula, the same fp32 operation order)
+    float    nrm[16];   // transpose(inverse): normals
+    bool     identity = false;
+    uint32_t blas = 0, primBase = 0, instanceId = 0;
+    Box      world;     // conservative world-space box (only used to skip instances; never decides a hit)
+};
+
 struct orc_scene
 {
     std::vector<prt_vertex>   verts;
@@ -144,12 +166,10 @@ struct orc_scene
     uint32_t                  seed      = 1;
     const uint32_t*           scrTable  = nullptr;
     uint32_t                  scrW = 0, scrH = 0;
-    // BVH
-    std::vector<orc_node> nodes;
-    std::vector<uint32_t> order;
-    uint32_t              depth     = 0;
-    float                 sceneAbs  = 0.0f;
-    size_t                ntri() const { return idx.size() / 3; }
+    Geo                       geo;   // single-level: the whole scene
+    std::vector<Geo>          blas;  // two-level: bottom-level structures ...
+    std::vector<Inst>         inst;  // ... and their instances (empty = single-level)
+    size_t                    ntri() const { return idx.size() / 3; }
 };
 
 namespace {
@@ -237,9 +257,9 @@ inline float boxArea(const Box& b)
     return ((dx * dy) + (dy * dz)) + (dz * dx);
 }
 
-int buildBVH(orc_scene& sc)
+int buildBVH(const orc_scene& scene, Geo& sc)
 {
-    const uint32_t N = (uint32_t)sc.ntri();
+    const uint32_t N = sc.nTri;
     sc.nodes.clear();
     sc.order.resize(N);
     if(N == 0)
@@ -252,7 +272,7 @@ int buildBVH(orc_scene& sc)
         boxEmpty(b);
         for(int k = 0; k < 3; ++k)
         {
-            const float* p = sc.verts[sc.idx[3 * i + k]].p;
+            const float* p = scene.verts[scene.idx[3 * (size_t)(sc.firstTri + i) + k]].p;
             for(int a = 0; a < 3; ++a)
             {
                 b.mn[a] = kmin(b.mn[a], p[a]);
@@ -433,7 +453,7 @@ struct RayPre
     float amax;  // max(|scene|, |origin|): scale of the pads
 };
 
-inline void rayPrepare(const orc_scene& sc, const float o[3], const float d[3], RayPre& r)
+inline void rayPrepare(float sceneAbs, const float o[3], const float d[3], RayPre& r)
 {
     for(int k = 0; k < 3; ++k)
     {
@@ -464,7 +484,7 @@ inline void rayPrepare(const orc_scene& sc, const float o[3], const float d[3], 
     r.Sy = d[ky] / d[kz];
     r.Sz = 1.0f / d[kz];
     // conservative slab set-up: boxes are grown by `pad` and the slab distances widened by 4 ulp
-    float amax = sc.sceneAbs;
+    float amax = sceneAbs;
     for(int k = 0; k < 3; ++k)
         amax = gmax(amax, gabs(o[k]));
     const float pad = 3.814697265625e-06f * amax;  // 64 * 2^-24
@@ -565,50 +585,52 @@ inline bool triTest(const RayPre& r, const float* p0, const float* p1, const flo
     return true;
 }
 
-inline const float* triVertex(const orc_scene& sc, uint32_t prim, int k) { return sc.verts[sc.idx[3 * prim + k]].p; }
+inline const float* triVertex(const orc_scene& sc, const Geo& g, uint32_t prim, int k)
+{
+    return sc.verts[sc.idx[3 * (size_t)(g.firstTri + prim) + k]].p;
+}
 
-orc_hit traceClosest(const orc_scene& sc, const float o[3], float tmin, const float d[3], float tmax, bool brute)
+// Closest hit inside ONE structure, ray given in the structure's space. `best` carries the closest hit so far (and
+// bounds the search); primitive ids are reported as primBase + local id.
+void traceClosestGeo(const orc_scene& sc, const Geo& g, const float o[3], float tmin, const float d[3], float tmax,
+                     bool brute, uint32_t primBase, orc_hit& best)
 {
     RayPre r;
-    rayPrepare(sc, o, d, r);
-    orc_hit best;
-    best.prim = 0xffffffffu;
-    best.u = best.v = 0.0f;
-    best.t          = tmax;
-    auto testPrim   = [&](uint32_t p) {
+    rayPrepare(g.sceneAbs, o, d, r);
+    auto testPrim = [&](uint32_t p) {
         float t, u, v;
-        if(triTest(r, triVertex(sc, p, 0), triVertex(sc, p, 1), triVertex(sc, p, 2), tmin, tmax, t, u, v))
+        if(triTest(r, triVertex(sc, g, p, 0), triVertex(sc, g, p, 1), triVertex(sc, g, p, 2), tmin, tmax, t, u, v))
         {
-            if(t < best.t || (t == best.t && p < best.prim))
+            if(t < best.t || (t == best.t && primBase + p < best.prim))
             {
                 best.t    = t;
                 best.u    = u;
                 best.v    = v;
-                best.prim = p;
+                best.prim = primBase + p;
             }
         }
     };
     if(brute)
     {
-        for(uint32_t p = 0; p < sc.ntri(); ++p)
+        for(uint32_t p = 0; p < g.nTri; ++p)
             testPrim(p);
-        return best;
+        return;
     }
     uint32_t stack[128];
     int      sp  = 0;
     uint32_t cur = 0;
     for(;;)
     {
-        const orc_node& n = sc.nodes[cur];
+        const orc_node& n = g.nodes[cur];
         if(n.count > 0)
         {
             for(uint32_t i = 0; i < n.count; ++i)
-                testPrim(sc.order[n.first + i]);
+                testPrim(g.order[n.first + i]);
         }
         else
         {
-            const orc_node& L = sc.nodes[n.first];
-            const orc_node& R = sc.nodes[n.first + 1];
+            const orc_node& L = g.nodes[n.first];
+            const orc_node& R = g.nodes[n.first + 1];
             float           tl, tr;
             const bool      hl = slab(r, L.bmin, L.bmax, tmin, best.t, tl);
             const bool      hr = slab(r, R.bmin, R.bmax, tmin, best.t, tr);
@@ -641,18 +663,18 @@ orc_hit traceClosest(const orc_scene& sc, const float o[3], float tmin, const fl
             break;
         cur = stack[--sp];
     }
-    return best;
 }
 
-bool traceAny(const orc_scene& sc, const float o[3], float tmin, const float d[3], float tmax, bool brute)
+bool traceAnyGeo(const orc_scene& sc, const Geo& g, const float o[3], float tmin, const float d[3], float tmax,
+                 bool brute)
 {
     RayPre r;
-    rayPrepare(sc, o, d, r);
+    rayPrepare(g.sceneAbs, o, d, r);
     float t, u, v;
     if(brute)
     {
-        for(uint32_t p = 0; p < sc.ntri(); ++p)
-            if(triTest(r, triVertex(sc, p, 0), triVertex(sc, p, 1), triVertex(sc, p, 2), tmin, tmax, t, u, v))
+        for(uint32_t p = 0; p < g.nTri; ++p)
+            if(triTest(r, triVertex(sc, g, p, 0), triVertex(sc, g, p, 1), triVertex(sc, g, p, 2), tmin, tmax, t, u, v))
                 return true;
         return false;
     }
@@ -661,20 +683,20 @@ bool traceAny(const orc_scene& sc, const float o[3], float tmin, const float d[3
     uint32_t cur = 0;
     for(;;)
     {
-        const orc_node& n = sc.nodes[cur];
+        const orc_node& n = g.nodes[cur];
         if(n.count > 0)
         {
             for(uint32_t i = 0; i < n.count; ++i)
             {
-                const uint32_t p = sc.order[n.first + i];
-                if(triTest(r, triVertex(sc, p, 0), triVertex(sc, p, 1), triVertex(sc, p, 2), tmin, tmax, t, u, v))
+                const uint32_t p = g.order[n.first + i];
+                if(triTest(r, triVertex(sc, g, p, 0), triVertex(sc, g, p, 1), triVertex(sc, g, p, 2), tmin, tmax, t, u, v))
                     return true;
             }
         }
         else
         {
-            const orc_node& L = sc.nodes[n.first];
-            const orc_node& R = sc.nodes[n.first + 1];
+            const orc_node& L = g.nodes[n.first];
+            const orc_node& R = g.nodes[n.first + 1];
             float           tl, tr;
             const bool      hl = slab(r, L.bmin, L.bmax, tmin, tmax, tl);
             const bool      hr = slab(r, R.bmin, R.bmax, tmin, tmax, tr);
@@ -710,6 +732,95 @@ bool traceAny(const orc_scene& sc, const float o[3], float tmin, const float d[3
     return false;
 }
 
+// ---- instances (two-level scenes) ---------------------------------------------------------------
+// An instance is hit where its bottom-level structure is hit by the ray taken to OBJECT space:
+//   o' = (W0*o.x + W1*o.y) + (W2*o.z + W3),   d' = (W0*d.x + W1*d.y) + W2*d.z      (W = inverse transform, columns)
+// with the same t (d is not normalised, so the parameter is shared between the spaces, as in VK_NV_ray_tracing).
+// An instance whose transform is exactly the identity takes the ray as it is. The hit of the scene is the smallest t
+// over all instances, ties -> lower flattened primitive id (instance's base + local id). PARITY UNPINNED, like the
+// single-level trace: the reference never builds more than one identity instance (vkRTX_setup.cpp:138-186).
+inline void rayToObject(const Inst& in, const float o[3], const float d[3], float oo[3], float od[3])
+{
+    if(in.identity)
+    {
+        for(int k = 0; k < 3; ++k)
+        {
+            oo[k] = o[k];
+            od[k] = d[k];
+        }
+        return;
+    }
+    const float* W = in.w2o;
+    for(int k = 0; k < 3; ++k)
+    {
+        oo[k] = (W[0 + k] * o[0] + W[4 + k] * o[1]) + (W[8 + k] * o[2] + W[12 + k]);
+        od[k] = (W[0 + k] * d[0] + W[4 + k] * d[1]) + W[8 + k] * d[2];
+    }
+}
+
+// conservative "may the world ray touch this instance's box" (plain slab test with a generous margin)
+inline bool mayTouch(const Box& b, const float o[3], const float d[3], float tmin, float tmax)
+{
+    float tn = tmin, tf = tmax;
+    for(int k = 0; k < 3; ++k)
+    {
+        if(o[k] != o[k] || d[k] != d[k])
+            return true;  // let the exact test sort out NaN rays
+        if(gabs(d[k]) < 1e-20f)
+        {
+            if(o[k] < b.mn[k] || o[k] > b.mx[k])
+                return false;
+            continue;
+        }
+        const double a = ((double)b.mn[k] - (double)o[k]) / (double)d[k], c = ((double)b.mx[k] - (double)o[k]) / (double)d[k];
+        const double lo = a < c ? a : c, hi = a < c ? c : a;
+        const double m  = 1e-5 * ((lo < 0 ? -lo : lo) + (hi < 0 ? -hi : hi)) + 1e-30;
+        if(lo - m > tn)
+            tn = (float)(lo - m);
+        if(hi + m < tf)
+            tf = (float)(hi + m);
+    }
+    return tn <= tf * 1.00001f + 1e-30f;
+}
+
+orc_hit traceClosest(const orc_scene& sc, const float o[3], float tmin, const float d[3], float tmax, bool brute)
+{
+    orc_hit best;
+    best.prim = 0xffffffffu;
+    best.u = best.v = 0.0f;
+    best.t          = tmax;
+    if(sc.inst.empty())
+    {
+        traceClosestGeo(sc, sc.geo, o, tmin, d, tmax, brute, 0u, best);
+        return best;
+    }
+    for(const Inst& in : sc.inst)
+    {
+        if(!brute && !mayTouch(in.world, o, d, tmin, best.t))
+            continue;
+        float oo[3], od[3];
+        rayToObject(in, o, d, oo, od);
+        traceClosestGeo(sc, sc.blas[in.blas], oo, tmin, od, tmax, brute, in.primBase, best);
+    }
+    return best;
+}
+
+bool traceAny(const orc_scene& sc, const float o[3], float tmin, const float d[3], float tmax, bool brute)
+{
+    if(sc.inst.empty())
+        return traceAnyGeo(sc, sc.geo, o, tmin, d, tmax, brute);
+    for(const Inst& in : sc.inst)
+    {
+        if(!brute && !mayTouch(in.world, o, d, tmin, tmax))
+            continue;
+        float oo[3], od[3];
+        rayToObject(in, o, d, oo, od);
+        if(traceAnyGeo(sc, sc.blas[in.blas], oo, tmin, od, tmax, brute))
+            return true;
+    }
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------------
 // shader helpers
 // ------------------------------------------------------------------------------------------------
@@ -727,6 +838,46 @@ inline Vertex unpackVertex(const orc_scene& sc, uint32_t index)
     v.normal   = V3(s.n[0], s.n[1], s.n[2]);
     v.texCoord = vec2{s.t[0], s.t[1]};
     v.matIndex = s.materialID;
+    return v;
+}
+
+// Corner k of the (flattened) primitive `prim` as the shaders see it. Single-level: the scene's vertex. Two-level: the
+// primitive is `prim - primBase` of its instance's bottom-level structure, taken to world space the way an instanced
+// scene is flattened (pathtracer_amd/host/Scene.cpp): p = (M0*x + M1*y) + (M2*z + M3), n = normalize(N * n) with
+// N = transpose(inverse(M)) (a zero normal stays zero); texture coordinates and material unchanged; an identity
+// instance is taken bit for bit.
+inline const Inst& instanceOf(const orc_scene& sc, uint32_t prim)
+{
+    size_t lo = 0, hi = sc.inst.size();  // last instance whose primBase <= prim
+    while(hi - lo > 1)
+    {
+        const size_t mid = (lo + hi) / 2;
+        if(sc.inst[mid].primBase <= prim)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return sc.inst[lo];
+}
+inline Vertex shadingVertex(const orc_scene& sc, uint32_t prim, int k)
+{
+    if(sc.inst.empty())
+        return unpackVertex(sc, sc.idx[3 * (size_t)prim + k]);
+    const Inst& in    = instanceOf(sc, prim);
+    const Geo&  g     = sc.blas[in.blas];
+    Vertex      v     = unpackVertex(sc, sc.idx[3 * (size_t)(g.firstTri + (prim - in.primBase)) + k]);
+    if(!in.identity)
+    {
+        const float *M = in.o2w, *N = in.nrm;
+        const vec3   p = v.pos, n = v.normal;
+        v.pos = V3((M[0] * p.x + M[4] * p.y) + (M[8] * p.z + M[12]), (M[1] * p.x + M[5] * p.y) + (M[9] * p.z + M[13]),
+                   (M[2] * p.x + M[6] * p.y) + (M[10] * p.z + M[14]));
+        vec3 nn = V3((N[0] * n.x + N[4] * n.y) + N[8] * n.z, (N[1] * n.x + N[5] * n.y) + N[9] * n.z,
+                     (N[2] * n.x + N[6] * n.y) + N[10] * n.z);
+        if(dot(nn, nn) > 0.0f)
+            nn = normalize(nn);
+        v.normal = nn;
+    }
     return v;
 }
 
@@ -1011,9 +1162,9 @@ void aoPixel(PixelCtx& cx, uint32_t px, uint32_t py, float* Eio, uint32_t* hitId
     scramble[1]         = scrambleValue(sc, px, py, cx.w, cx.h, 1);
     uint32_t sobolIndex = scrambleValue(sc, px, py, cx.w, cx.h, 2);
 
-    const Vertex v0 = unpackVertex(sc, sc.idx[3 * hit.prim + 0]);
-    const Vertex v1 = unpackVertex(sc, sc.idx[3 * hit.prim + 1]);
-    const Vertex v2 = unpackVertex(sc, sc.idx[3 * hit.prim + 2]);
+    const Vertex v0 = shadingVertex(sc, hit.prim, 0);
+    const Vertex v1 = shadingVertex(sc, hit.prim, 1);
+    const Vertex v2 = shadingVertex(sc, hit.prim, 2);
     const vec3   bary = V3(1.0f - hit.u - hit.v, hit.u, hit.v);
     vec3         normal = normalize((v0.normal * bary.x + v1.normal * bary.y) + v2.normal * bary.z);
     if(dot(normal, Rd) > 0.0f)
@@ -1141,9 +1292,9 @@ void pathPixel(PixelCtx& cx, uint32_t px, uint32_t py, float* Eio, uint32_t* hit
             const vec3     barycentrics = V3(1.0f - payload.u - payload.v, payload.u, payload.v);  // pathRT.rchit:19
             const uint32_t* scramble    = scrambleArray[scrambleArrayLayer++];
 
-            const Vertex v0 = unpackVertex(sc, sc.idx[3 * primitiveID + 0]);
-            const Vertex v1 = unpackVertex(sc, sc.idx[3 * primitiveID + 1]);
-            const Vertex v2 = unpackVertex(sc, sc.idx[3 * primitiveID + 2]);
+            const Vertex v0 = shadingVertex(sc, primitiveID, 0);
+            const Vertex v1 = shadingVertex(sc, primitiveID, 1);
+            const Vertex v2 = shadingVertex(sc, primitiveID, 2);
 
             // out-of-range material / texture ids are undefined behaviour in the shader; defined here as
             // "material 0" / "no texture".
@@ -1384,6 +1535,17 @@ void parallelRows(uint32_t n, int threads, F&& f)
 
 }  // namespace
 
+// max |coordinate| over the triangles of a range: what buildBVH derives from the root box, available before a build
+// so that brute-force traces use the same pads
+static float rangeAbs(const orc_scene& sc, uint32_t first, uint32_t n)
+{
+    float a = 0.0f;
+    for(size_t i = (size_t)3 * first; i < (size_t)3 * (first + n); ++i)
+        for(int k = 0; k < 3; ++k)
+            a = gmax(a, gabs(sc.verts[sc.idx[i]].p[k]));
+    return a;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C interface
 // ------------------------------------------------------------------------------------------------
@@ -1404,6 +1566,9 @@ orc_scene* orc_scene_create(const prt_vertex* v, size_t nv, const uint32_t* idx,
         t.rgba.assign(tex[i].rgba, tex[i].rgba + (size_t)t.w * t.h * 4);
         sc->tex.push_back(std::move(t));
     }
+    sc->geo.firstTri = 0;
+    sc->geo.nTri     = (uint32_t)sc->ntri();
+    sc->geo.sceneAbs = rangeAbs(*sc, 0, sc->geo.nTri);
     return sc;
 }
 void orc_scene_destroy(orc_scene* sc) { delete sc; }
@@ -1426,15 +1591,147 @@ void orc_set_scramble_table(orc_scene* sc, const uint32_t* table, uint32_t w, ui
     sc->scrH     = h;
 }
 
-int      orc_build_bvh(orc_scene* sc) { return buildBVH(*sc); }
-uint32_t orc_bvh_num_nodes(const orc_scene* sc) { return (uint32_t)sc->nodes.size(); }
-uint32_t orc_bvh_depth(const orc_scene* sc) { return sc->depth; }
+// glm 0.9.9.5 detail/func_matrix.inl compute_inverse<4,4> (cofactors, then * 1/determinant), same operation order;
+// a = column-major 4x4. The host layer's prt_math.h restates the same function and is pinned against glm itself
+// (tests/golden/host_golden.json); tests/test_oracle_cpu.py compares the two.
+void orc_inverse4(const float* a, float* out)
+{
+#define M(c, r) a[(c)*4 + (r)]
+    const float c00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3), c02 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3);
+    const float c03 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3), c04 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3);
+    const float c06 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3), c07 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3);
+    const float c08 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2), c10 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2);
+    const float c11 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2), c12 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3);
+    const float c14 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3), c15 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3);
+    const float c16 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2), c18 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2);
+    const float c19 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2), c20 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1);
+    const float c22 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1), c23 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
+    const float F0[4] = {c00, c00, c02, c03}, F1[4] = {c04, c04, c06, c07}, F2[4] = {c08, c08, c10, c11};
+    const float F3[4] = {c12, c12, c14, c15}, F4[4] = {c16, c16, c18, c19}, F5[4] = {c20, c20, c22, c23};
+    const float V0[4] = {M(1, 0), M(0, 0), M(0, 0), M(0, 0)}, V1[4] = {M(1, 1), M(0, 1), M(0, 1), M(0, 1)};
+    const float V2[4] = {M(1, 2), M(0, 2), M(0, 2), M(0, 2)}, V3[4] = {M(1, 3), M(0, 3), M(0, 3), M(0, 3)};
+    float       inv[16];
+    for(int j = 0; j < 4; ++j)
+    {
+        const float sa = (j & 1) ? -1.0f : 1.0f, sb = -sa;
+        inv[0 + j]  = ((V1[j] * F0[j] - V2[j] * F1[j]) + V3[j] * F2[j]) * sa;
+        inv[4 + j]  = ((V0[j] * F0[j] - V2[j] * F3[j]) + V3[j] * F4[j]) * sb;
+        inv[8 + j]  = ((V0[j] * F1[j] - V1[j] * F3[j]) + V3[j] * F5[j]) * sa;
+        inv[12 + j] = ((V0[j] * F2[j] - V1[j] * F4[j]) + V2[j] * F5[j]) * sb;
+    }
+    const float d0 = M(0, 0) * inv[0], d1 = M(0, 1) * inv[4], d2 = M(0, 2) * inv[8], d3 = M(0, 3) * inv[12];
+    const float det = (d0 + d1) + (d2 + d3);
+    const float ood = 1.0f / det;
+    for(int k = 0; k < 16; ++k)
+        out[k] = inv[k] * ood;
+#undef M
+}
+
+/* Two-level scene: `blas` = ranges of the scene's triangles (object space), `inst` = instances of them. Primitive
+ * ids reported by traces and renders are flattened: instance i's triangles follow those of instances 0..i-1.
+ * n_inst == 0 returns to the single-level scene. Call orc_build_bvh afterwards. Returns 0, or -1 on a bad range /
+ * index. */
+int orc_set_instances(orc_scene* sc, const prt_blas_range* blas, size_t n_blas, const prt_instance* inst, size_t n_inst)
+{
+    sc->blas.clear();
+    sc->inst.clear();
+    if(n_inst == 0)
+        return 0;
+    for(size_t k = 0; k < n_blas; ++k)
+    {
+        if(blas[k].n_triangles == 0 || (size_t)blas[k].first_triangle + blas[k].n_triangles > sc->ntri())
+            return -1;
+        Geo g;
+        g.firstTri = blas[k].first_triangle;
+        g.nTri     = blas[k].n_triangles;
+        g.sceneAbs = rangeAbs(*sc, g.firstTri, g.nTri);
+        sc->blas.push_back(std::move(g));
+    }
+    uint64_t base = 0;
+    for(size_t i = 0; i < n_inst; ++i)
+    {
+        if(inst[i].blas >= n_blas)
+        {
+            sc->blas.clear();
+            sc->inst.clear();
+            return -1;
+        }
+        Inst in;
+        memcpy(in.o2w, inst[i].transform, 64);
+        static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        in.identity = memcmp(in.o2w, ident, 64) == 0;
+        orc_inverse4(in.o2w, in.w2o);
+        for(int c = 0; c < 4; ++c)
+            for(int r = 0; r < 4; ++r)
+                in.nrm[c * 4 + r] = in.w2o[r * 4 + c];
+        in.blas       = inst[i].blas;
+        in.instanceId = inst[i].instance_id;
+        in.primBase   = (uint32_t)base;
+        base += sc->blas[in.blas].nTri;
+        boxEmpty(in.world);
+        sc->inst.push_back(in);
+    }
+    return base < 0xffffffffull ? 0 : -1;
+}
+
+int orc_build_bvh(orc_scene* sc)
+{
+    if(sc->inst.empty())
+    {
+        sc->geo.firstTri = 0;
+        sc->geo.nTri     = (uint32_t)sc->ntri();
+        return buildBVH(*sc, sc->geo);
+    }
+    for(Geo& g : sc->blas)
+        if(buildBVH(*sc, g))
+            return -1;
+    // world boxes of the instances: the 8 corners of the structure's box, transformed in double, with a margin
+    for(Inst& in : sc->inst)
+    {
+        const orc_node& root = sc->blas[in.blas].nodes[0];
+        boxEmpty(in.world);
+        double ext = 0.0;
+        for(int c = 0; c < 8; ++c)
+        {
+            const double p[3] = {(c & 1) ? root.bmax[0] : root.bmin[0], (c & 2) ? root.bmax[1] : root.bmin[1],
+                                 (c & 4) ? root.bmax[2] : root.bmin[2]};
+            for(int k = 0; k < 3; ++k)
+            {
+                const double w = (double)in.o2w[0 + k] * p[0] + (double)in.o2w[4 + k] * p[1] + (double)in.o2w[8 + k] * p[2] +
+                                 (double)in.o2w[12 + k];
+                if(w < in.world.mn[k]) in.world.mn[k] = (float)w;
+                if(w > in.world.mx[k]) in.world.mx[k] = (float)w;
+                ext = std::fmax(ext, std::fabs(w));
+            }
+        }
+        const float m = (float)(ext * 1e-3 + 1e-6);
+        for(int k = 0; k < 3; ++k)
+        {
+            in.world.mn[k] = std::nextafter(in.world.mn[k], -INFINITY) - m;
+            in.world.mx[k] = std::nextafter(in.world.mx[k], INFINITY) + m;
+        }
+    }
+    return 0;
+}
+uint32_t orc_bvh_num_nodes(const orc_scene* sc) { return (uint32_t)sc->geo.nodes.size(); }
+uint32_t orc_bvh_depth(const orc_scene* sc) { return sc->geo.depth; }
 void     orc_bvh_read(const orc_scene* sc, orc_node* nodes_out, uint32_t* order_out)
 {
     if(nodes_out)
-        memcpy(nodes_out, sc->nodes.data(), sc->nodes.size() * sizeof(orc_node));
+        memcpy(nodes_out, sc->geo.nodes.data(), sc->geo.nodes.size() * sizeof(orc_node));
     if(order_out)
-        memcpy(order_out, sc->order.data(), sc->order.size() * 4);
+        memcpy(order_out, sc->geo.order.data(), sc->geo.order.size() * 4);
+}
+/* the same for bottom-level structure k of a two-level scene (order: ids local to the structure's range) */
+uint32_t orc_blas_num_nodes(const orc_scene* sc, uint32_t k) { return k < sc->blas.size() ? (uint32_t)sc->blas[k].nodes.size() : 0u; }
+void     orc_blas_read(const orc_scene* sc, uint32_t k, orc_node* nodes_out, uint32_t* order_out)
+{
+    if(k >= sc->blas.size())
+        return;
+    if(nodes_out)
+        memcpy(nodes_out, sc->blas[k].nodes.data(), sc->blas[k].nodes.size() * sizeof(orc_node));
+    if(order_out)
+        memcpy(order_out, sc->blas[k].order.data(), sc->blas[k].order.size() * 4);
 }
 
 float orc_sobol_sample(const orc_scene* sc, uint32_t index, uint32_t dim, uint32_t scramble)

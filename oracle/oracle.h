@@ -67,6 +67,16 @@ void orc_set_sobol(orc_scene*, const uint32_t* matrices, uint32_t dims, uint32_t
 void orc_set_scramble_seed(orc_scene*, uint32_t seed);
 void orc_set_scramble_table(orc_scene*, const uint32_t* table, uint32_t w, uint32_t h);
 
+/* Two-level scenes (vkRT_TLAS.cpp:58-72 AddInstance; the reference itself wires one identity instance,
+ * vkRTX_setup.cpp:138-186): `blas` = ranges of the scene's triangles in object space, `inst` = instances of them.
+ * A ray is taken to object space with the inverse transform (same t) and tested there; the scene's hit is the smallest
+ * t over all instances, ties -> lower flattened primitive id (instance i's triangles follow those of instances
+ * 0..i-1). n_inst == 0 returns to the single-level scene. Call orc_build_bvh afterwards. 0, or -1 on a bad range. */
+int  orc_set_instances(orc_scene*, const prt_blas_range* blas, size_t n_blas, const prt_instance* inst, size_t n_inst);
+void orc_inverse4(const float* m16, float* out16); /* glm::inverse(mat4), column-major */
+uint32_t orc_blas_num_nodes(const orc_scene*, uint32_t k);
+void     orc_blas_read(const orc_scene*, uint32_t k, orc_node* nodes_out, uint32_t* order_out);
+
 int      orc_build_bvh(orc_scene*);
 uint32_t orc_bvh_num_nodes(const orc_scene*);
 void     orc_bvh_read(const orc_scene*, orc_node* nodes_out, uint32_t* order_out);

@@ -18,6 +18,10 @@ NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("first", "<u4"), ("bmax", "<f4", 3),
 HIT_DTYPE = np.dtype([("prim", "<u4"), ("u", "<f4"), ("v", "<f4"), ("t", "<f4")])
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("tmin", "<f4"), ("d", "<f4", 3), ("tmax", "<f4")])
 
+BLAS_DTYPE = np.dtype([("first_triangle", "<u4"), ("n_triangles", "<u4")])
+INSTANCE_DTYPE = np.dtype([("transform", "<f4", 16), ("blas", "<u4"), ("instance_id", "<u4"), ("hit_group", "<u4"),
+                           ("pad", "<u4")])
+
 FLAG_LITERAL = 1
 FLAG_RUSSIAN_ROULETTE = 2
 FLAG_BRUTE_FORCE = 4
@@ -67,6 +71,12 @@ def lib():
         L.orc_render.argtypes = [vp, vp, u32, u32, i32, u32, vp, vp, i32]
         L.orc_render.restype = C.c_uint64
         L.orc_postprocess.argtypes = [vp, u32, u32, vp]
+        L.orc_set_instances.argtypes = [vp, vp, sz, vp, sz]
+        L.orc_set_instances.restype = i32
+        L.orc_inverse4.argtypes = [vp, vp]
+        L.orc_blas_num_nodes.argtypes = [vp, u32]
+        L.orc_blas_num_nodes.restype = u32
+        L.orc_blas_read.argtypes = [vp, u32, vp, vp]
         _LIB = L
     return _LIB
 
@@ -120,6 +130,23 @@ class Oracle:
         table = np.ascontiguousarray(table, dtype=np.uint32)
         self._keep.append(table)
         lib().orc_set_scramble_table(self.h, _ptr(table), w, h)
+
+    def set_instances(self, blas, instances):
+        """Two-level scene: blas = BLAS_DTYPE array (triangle ranges), instances = INSTANCE_DTYPE array
+        (transform = column-major mat4 object -> world). Empty instances: back to the single-level scene."""
+        b = np.ascontiguousarray(blas, dtype=BLAS_DTYPE)
+        i = np.ascontiguousarray(instances, dtype=INSTANCE_DTYPE)
+        if lib().orc_set_instances(self.h, _ptr(b), len(b), _ptr(i), len(i)) != 0:
+            raise RuntimeError("orc_set_instances: bad range or index")
+        self._blas = b
+        self.built = False
+
+    def blas_bvh(self, k):
+        n = lib().orc_blas_num_nodes(self.h, k)
+        nodes = np.zeros(n, NODE_DTYPE)
+        order = np.zeros(int(self._blas[k]["n_triangles"]), np.uint32)
+        lib().orc_blas_read(self.h, k, _ptr(nodes), _ptr(order))
+        return nodes, order
 
     def build_bvh(self):
         rc = lib().orc_build_bvh(self.h)
@@ -176,6 +203,13 @@ def primary_ray(ubo, px, py, w, h, varx=0.5, vary=0.5):
     out = np.zeros((), RAY_DTYPE)
     ubo = np.ascontiguousarray(ubo)
     lib().orc_primary_ray(_ptr(ubo), px, py, w, h, varx, vary, _ptr(out))
+    return out
+
+
+def inverse4(m):
+    a = np.ascontiguousarray(m, dtype=np.float32).reshape(16)
+    out = np.zeros(16, np.float32)
+    lib().orc_inverse4(_ptr(a), _ptr(out))
     return out
 
 

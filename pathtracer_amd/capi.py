@@ -16,6 +16,7 @@ FLAG_LITERAL, FLAG_RUSSIAN_ROULETTE = 1, 2
 BVH_NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("first", "<u4"), ("bmax", "<f4", 3), ("count", "<u4")])
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("tmin", "<f4"), ("d", "<f4", 3), ("tmax", "<f4")])
 HIT_DTYPE = np.dtype([("prim", "<u4"), ("u", "<f4"), ("v", "<f4"), ("t", "<f4")])
+from .scenes import BLAS_DTYPE, INSTANCE_DTYPE  # include/prt_types.h: prt_blas_range, prt_instance  # noqa: E402
 
 EXPORTS = [
     "prt_create", "prt_destroy", "prt_last_error", "prt_set_scene", "prt_build_accel", "prt_set_scramble_seed",
@@ -27,7 +28,7 @@ EXPORTS = [
     "prt_group_create", "prt_group_destroy", "prt_group_last_error", "prt_group_size", "prt_group_uses_rccl",
     "prt_group_context", "prt_group_set_scene", "prt_group_set_scramble_seed", "prt_group_set_uniforms",
     "prt_group_set_flags", "prt_group_clear_accum", "prt_group_render", "prt_group_reduce", "prt_group_read_accum",
-    "prt_group_get_stats",
+    "prt_group_get_stats", "prt_set_instances", "prt_update_instance_transforms", "prt_read_blas_bvh",
 ]
 
 K_GENERATE, K_EXTEND, K_SHADE, K_SHADOW, K_AO_SHADE, K_RESOLVE, K_SHADOW_EXTEND, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 8
@@ -108,6 +109,9 @@ def lib():
         L.prt_update_vertices.argtypes = [vp, vp, sz]
         L.prt_refit_accel.argtypes = [vp]
         L.prt_write_accum.argtypes = [vp, vp]
+        L.prt_set_instances.argtypes = [vp, vp, sz, vp, sz]
+        L.prt_update_instance_transforms.argtypes = [vp, vp, sz]
+        L.prt_read_blas_bvh.argtypes = [vp, u32, vp, vp, C.POINTER(u32)]
         L.prt_group_create.argtypes = [i32, C.POINTER(i32), u32, u32, C.POINTER(vp)]
         L.prt_group_destroy.argtypes = [vp]
         L.prt_group_last_error.argtypes = [vp]
@@ -183,6 +187,26 @@ class Context:
         self._chk(self.L.prt_set_scene(self.h_, _ptr(v), len(v), _ptr(i), len(i), _ptr(m), len(m),
                                        C.addressof(arr), len(texs)))
         self.ntri = len(i) // 3
+
+    def set_instances(self, blas, instances):
+        """Two-level scene (call between set_scene and build_accel): blas = BLAS_DTYPE array of triangle ranges,
+        instances = INSTANCE_DTYPE array. Empty instances: back to the single-level scene."""
+        b = np.ascontiguousarray(blas, dtype=BLAS_DTYPE)
+        i = np.ascontiguousarray(instances, dtype=INSTANCE_DTYPE)
+        self._chk(self.L.prt_set_instances(self.h_, _ptr(b), len(b), _ptr(i), len(i)))
+        self._blas = b
+
+    def update_instance_transforms(self, transforms):
+        t = np.ascontiguousarray(transforms, dtype=np.float32).reshape(-1, 16)
+        self._chk(self.L.prt_update_instance_transforms(self.h_, _ptr(t), len(t)))
+
+    def read_blas_bvh(self, k):
+        n = C.c_uint32()
+        self._chk(self.L.prt_read_blas_bvh(self.h_, k, None, None, C.byref(n)))
+        nodes = np.zeros(n.value, BVH_NODE_DTYPE)
+        order = np.zeros(int(self._blas[k]["n_triangles"]), np.uint32)
+        self._chk(self.L.prt_read_blas_bvh(self.h_, k, _ptr(nodes), _ptr(order), None))
+        return nodes, order
 
     def build_accel(self):
         self._chk(self.L.prt_build_accel(self.h_))

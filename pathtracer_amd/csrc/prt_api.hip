@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -13,6 +14,7 @@
 #include <vector>
 
 #include "../../include/prt.h"
+#include "../host/prt_math.h"  // glm's inverse(mat4) with the same operation order (pinned against glm: tests/golden)
 #include "prt_bvh.hpp"
 #include "prt_kernels.hpp"
 #include "sobol_table.hpp"
@@ -74,6 +76,23 @@ struct Pipe
     bool       allocated = false, busy = false;  // busy: a resolve that frees the pipe has been enqueued
 };
 
+// A binary build tree over N primitives (the triangles of a range of the scene, or the instance boxes of the top
+// level) and what its traversal layout needs. The build nodes and the order stay for refits and inspection.
+struct Tree
+{
+    BuildNode* dBuildNodes = nullptr;
+    uint32_t*  dOrder      = nullptr;
+    uint32_t   first = 0, N = 0;  // triangle range (N instances for the top level)
+    uint32_t   nNodes = 0, nInner = 0, depth = 0;
+    LevelTable lt{};
+    QuantGrid  grid{};
+    float      sceneAbs = 0.0f;
+    float      bmin[3] = {0.0f, 0.0f, 0.0f}, bmax[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t   nodeBase = 0, slotBase = 0;  // position in the node / leaf arrays shared by all structures
+    int32_t    root = 0;
+    uint32_t*  dWideIdx = nullptr;  // between tree_layout and tree_emit: BVH4 index of every build node
+};
+
 struct prt_context
 {
     int         device = 0;
@@ -97,16 +116,23 @@ struct prt_context
     bool          haveScene = false, haveAccel = false;
     bool          accelStale = false;  // vertices replaced since the last build / refit
 
-    // acceleration structure
-    BuildNode* dBuildNodes = nullptr;
-    uint32_t*  dOrder      = nullptr;
+    // acceleration structure. Single-level: `top` is the tree over all triangles. Two-level (prt_set_instances):
+    // `top` is the tree over the instances' world boxes, `blas` the trees of the bottom-level structures; all of them
+    // are laid out in the one node array / leaf array the kernels see.
+    Tree              top;
+    std::vector<Tree> blas;
     uint4*     dNodes      = nullptr;  // BVH4, 4 x uint4 per node
-    QuantGrid  grid{};
     float4*    dTris       = nullptr;
-    uint32_t   nNodes = 0, nInner = 0, depth = 0;
-    int32_t    root     = 0;
-    float      sceneAbs = 0.0f, buildMs = 0.0f, refitMs = 0.0f;
-    LevelTable lt{};
+    float      buildMs = 0.0f, refitMs = 0.0f;
+    // instances (two-level scenes)
+    std::vector<prt_blas_range> blasRanges;
+    std::vector<prt_instance>   instances;
+    float4*   dInst      = nullptr;  // traversal records, top-level leaf order (prt_trace.hpp InstanceRec)
+    float4*   dShadeInst = nullptr;  // shading records, caller's order (prt_kernels.hpp ShadeInst)
+    uint32_t* dInstBase  = nullptr;  // flattened primitive id of every instance's first triangle, + total
+    float     padScale   = 1.0f;
+    bool      twoLevel() const { return !instances.empty(); }
+    uint32_t  gridTwo[6] = {0, 0, 0, 0, 0, 0};  // resident grids of the two-level kernel variants
 
     // sampling
     uint32_t* dSobol    = nullptr;
@@ -277,6 +303,25 @@ static TraceTune trace_tune()
     return t;
 }
 
+static void tree_free(Tree& t)
+{
+    dfree(t.dBuildNodes);
+    dfree(t.dOrder);
+    dfree(t.dWideIdx);
+    t = Tree();
+}
+static void free_accel(prt_context* c)
+{
+    tree_free(c->top);
+    for(Tree& t : c->blas) tree_free(t);
+    c->blas.clear();
+    dfree(c->dNodes);
+    dfree(c->dTris);
+    dfree(c->dInst);
+    dfree(c->dShadeInst);
+    dfree(c->dInstBase);
+    c->haveAccel = false;
+}
 static void free_scene(prt_context* c)
 {
     dfree(c->dVerts);
@@ -286,11 +331,10 @@ static void free_scene(prt_context* c)
     dfree(c->dShadeTris);
     for(void* p : c->texMem) (void)hipFree(p);
     c->texMem.clear();
-    dfree(c->dBuildNodes);
-    dfree(c->dOrder);
-    dfree(c->dNodes);
-    dfree(c->dTris);
-    c->haveScene = c->haveAccel = false;
+    free_accel(c);
+    c->blasRanges.clear();
+    c->instances.clear();
+    c->haveScene = false;
 }
 
 extern "C" {
@@ -328,11 +372,11 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
         c->gridExtend = resident((const void*)k_extend<false>);
         c->gridShadow = resident((const void*)k_shadow<false>);
         c->gridBatch  = resident((const void*)k_trace_batch<false>);
-        c->gridAo     = resident((const void*)k_ao_shade);
+        c->gridAo     = resident((const void*)k_ao_shade<false>);
         c->gridFused  = resident((const void*)k_shadow_extend<false>);
         // k_shade strides over its queue with a fixed stride: every block must be resident from the start, or the
         // late blocks do their whole share on a nearly empty GPU
-        c->gridShade  = resident((const void*)k_shade);
+        c->gridShade  = resident((const void*)k_shade<false>);
         if(const char* g = getenv("PRT_SHADE_BLOCKS_PER_CU"))
         {
             const int nb = atoi(g);
@@ -490,31 +534,128 @@ static int device_scan(prt_context* c, uint32_t* data, uint32_t n, uint32_t* til
     return PRT_OK;
 }
 
-// traversal layout of the current build tree: BVH4 with 16-bit boxes on the root box (see prt_bvh.hpp); shared by
-// prt_build_accel and prt_refit_accel
-static int emit_layout(prt_context* c)
-{
-    const uint32_t N = c->ntri, nNodes = c->nNodes;
-    hipStream_t    st = c->stream;
-    uint32_t *     flags = nullptr, *tileSums = nullptr, *total = nullptr;
-    auto           cleanup = [&]() { dfree(flags); dfree(tileSums); dfree(total); };
-#define BCHK(expr)                                                                                        \
-    do                                                                                                    \
-    {                                                                                                     \
-        hipError_t e_ = (expr);                                                                           \
-        if(e_ != hipSuccess)                                                                              \
-        {                                                                                                 \
-            cleanup();                                                                                    \
-            return fail(c, PRT_E_HIP, "acceleration structure layout: %s failed: %s", #expr, hipGetErrorString(e_)); \
-        }                                                                                                 \
+#define TCHK(expr)                                                                                          \
+    do                                                                                                      \
+    {                                                                                                       \
+        hipError_t e_ = (expr);                                                                             \
+        if(e_ != hipSuccess)                                                                                \
+        {                                                                                                   \
+            cleanup();                                                                                      \
+            return fail(c, PRT_E_HIP, "acceleration structure: %s failed: %s", #expr, hipGetErrorString(e_)); \
+        }                                                                                                   \
     } while(0)
-    BCHK(dalloc(flags, (size_t)nNodes));
-    BCHK(dalloc(tileSums, (size_t)cdiv((size_t)nNodes, PRT_SCAN_TILE) + 1));
-    BCHK(dalloc(total, (size_t)1));
-    int rc = PRT_OK;
+
+// Breadth-first binned-SAH build (prt_bvh.hpp) of one tree over t.N primitives: the triangles t.first .. t.first+N-1
+// of the scene, or, with `given`, N boxes (2 x float4 each: the instances of a two-level scene). Leaves hold at most
+// leafMax primitives. On success t holds build nodes, order, level table and depth.
+static int tree_build(prt_context* c, Tree& t, const float4* given, uint32_t leafMax, uint32_t maxDepth)
+{
+    const uint32_t  N   = t.N;
+    hipStream_t     st  = c->stream;
+    const uint32_t* idx = c->dIdx + (size_t)3 * t.first;
+    dfree(t.dBuildNodes);
+    dfree(t.dOrder);
+    dfree(t.dWideIdx);
+    const uint32_t maxSplit = N / (leafMax + 1) + 1;
+    uint32_t *     order2 = nullptr, *nodeOf = nullptr, *nodeOf2 = nullptr, *cb = nullptr, *bins = nullptr;
+    uint32_t *     flags = nullptr, *scanBuf = nullptr, *tileSums = nullptr, *rank = nullptr, *splitOf = nullptr;
+    uint32_t*      total = nullptr;
+    float4*        pbox  = nullptr;
+    SplitRec*      splits = nullptr;
+    int            rc     = PRT_OK;
+    auto           cleanup = [&]() {
+        dfree(order2); dfree(nodeOf); dfree(nodeOf2); dfree(cb); dfree(bins); dfree(flags); dfree(scanBuf);
+        dfree(tileSums); dfree(rank); dfree(splitOf); dfree(total); dfree(pbox); dfree(splits);
+    };
+    TCHK(dalloc(t.dBuildNodes, (size_t)2 * N));
+    TCHK(dalloc(t.dOrder, (size_t)N));
+    TCHK(dalloc(order2, (size_t)N));
+    TCHK(dalloc(nodeOf, (size_t)N));
+    TCHK(dalloc(nodeOf2, (size_t)N));
+    TCHK(dalloc(cb, (size_t)12 * N));
+    TCHK(dalloc(bins, (size_t)maxSplit * kBinWords));
+    TCHK(dalloc(flags, (size_t)2 * N));
+    TCHK(dalloc(scanBuf, (size_t)2 * N));
+    TCHK(dalloc(tileSums, (size_t)cdiv((size_t)2 * N, PRT_SCAN_TILE) + 1));
+    TCHK(dalloc(rank, (size_t)N));
+    TCHK(dalloc(splitOf, (size_t)N));
+    TCHK(dalloc(total, (size_t)1));
+    TCHK(dalloc(pbox, (size_t)2 * N));
+    TCHK(dalloc(splits, (size_t)maxSplit));
+
+    uint32_t* orderCur = t.dOrder;
+    uint32_t* orderAlt = order2;
+    hipLaunchKernelGGL(k_build_reset, dim3(1), dim3(64), 0, st, t.dBuildNodes, cb, N);
+    hipLaunchKernelGGL(k_prim_boxes, dim3(cdiv(N, 256)), dim3(256), 0, st, c->dVerts, idx, N, pbox, orderCur, nodeOf,
+                       t.dBuildNodes, cb, given);
+    uint32_t   levelStart = 0, levelCount = 1, nNodes = 1, depth = 1;
+    LevelTable lt;
+    memset(&lt, 0, sizeof lt);
+    for(;;)
+    {
+        lt.start[lt.n++] = levelStart;
+        hipLaunchKernelGGL(k_level_flags, dim3(cdiv(levelCount, 256)), dim3(256), 0, st, t.dBuildNodes, levelStart,
+                           levelCount, rank, leafMax);
+        rc = device_scan(c, rank, levelCount, tileSums, total);
+        if(rc) { cleanup(); return rc; }
+        uint32_t nsplit = 0;
+        TCHK(hipMemcpyAsync(&nsplit, total, 4, hipMemcpyDeviceToHost, st));
+        TCHK(hipStreamSynchronize(st));
+        if(nsplit == 0) break;
+        if(nsplit > maxSplit) { cleanup(); return fail(c, PRT_E_LIMIT, "prt_build_accel: split overflow"); }
+        hipLaunchKernelGGL(k_level_prepare, dim3(cdiv(levelCount, 256)), dim3(256), 0, st, t.dBuildNodes, levelStart,
+                           levelCount, rank, splits, leafMax);
+        hipLaunchKernelGGL(k_split_of, dim3(cdiv(levelCount, 256)), dim3(256), 0, st, t.dBuildNodes, levelStart,
+                           levelCount, rank, splitOf, leafMax);
+        hipLaunchKernelGGL(k_clear_bins, dim3(cdiv((size_t)nsplit * kBinWords, 256)), dim3(256), 0, st, bins, nsplit);
+        hipLaunchKernelGGL(k_bin, dim3(cdiv(N, 256)), dim3(256), 0, st, orderCur, nodeOf, t.dBuildNodes, cb, pbox, rank,
+                           levelStart, N, bins, leafMax);
+        hipLaunchKernelGGL(k_split, dim3(cdiv(nsplit, 64)), dim3(64), 0, st, t.dBuildNodes, cb, bins, splits, nsplit,
+                           nNodes);
+        hipLaunchKernelGGL(k_flags, dim3(cdiv(N, 256)), dim3(256), 0, st, orderCur, nodeOf, splitOf, splits,
+                           t.dBuildNodes, pbox, levelStart, N, flags, scanBuf);
+        rc = device_scan(c, scanBuf, N, tileSums, total);
+        if(rc) { cleanup(); return rc; }
+        hipLaunchKernelGGL(k_scatter, dim3(cdiv(N, 256)), dim3(256), 0, st, orderCur, nodeOf, splitOf, splits,
+                           t.dBuildNodes, cb, pbox, flags, scanBuf, levelStart, N, orderAlt, nodeOf2);
+        TCHK(hipGetLastError());
+        std::swap(orderCur, orderAlt);
+        std::swap(nodeOf, nodeOf2);
+        levelStart = nNodes;
+        levelCount = 2 * nsplit;
+        nNodes += 2 * nsplit;
+        depth++;
+        if(depth > maxDepth)
+        {
+            cleanup();
+            return fail(c, PRT_E_LIMIT, "prt_build_accel: tree deeper than %u levels", maxDepth);
+        }
+    }
+    if(orderCur != t.dOrder)
+        TCHK(hipMemcpyAsync(t.dOrder, orderCur, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+    TCHK(hipGetLastError());
+    TCHK(hipStreamSynchronize(st));
+    cleanup();
+    t.lt     = lt;
+    t.nNodes = nNodes;
+    t.depth  = depth;
+    return PRT_OK;
+}
+
+// What the traversal layout of a tree needs before it can be emitted: the root box (-> quantisation grid: BVH4 with
+// 16-bit boxes on the root box, see prt_bvh.hpp), and the BVH4 index of every build node (-> number of wide nodes).
+static int tree_layout(prt_context* c, Tree& t)
+{
+    hipStream_t st = c->stream;
+    uint32_t *  tileSums = nullptr, *total = nullptr;
+    dfree(t.dWideIdx);
+    auto cleanup = [&]() { dfree(tileSums); dfree(total); };
+    TCHK(dalloc(t.dWideIdx, (size_t)t.nNodes));
+    TCHK(dalloc(tileSums, (size_t)cdiv((size_t)t.nNodes, PRT_SCAN_TILE) + 1));
+    TCHK(dalloc(total, (size_t)1));
     BuildNode rootNode;
-    BCHK(hipMemcpyAsync(&rootNode, c->dBuildNodes, sizeof rootNode, hipMemcpyDeviceToHost, st));
-    BCHK(hipStreamSynchronize(st));
+    TCHK(hipMemcpyAsync(&rootNode, t.dBuildNodes, sizeof rootNode, hipMemcpyDeviceToHost, st));
+    TCHK(hipStreamSynchronize(st));
     auto dec = [](uint32_t k) {
         const uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
         float          f;
@@ -528,31 +669,246 @@ static int emit_layout(prt_context* c)
         sa             = sa < fabsf(lo) ? fabsf(lo) : sa;
         sa             = sa < fabsf(hi) ? fabsf(hi) : sa;
         const float ext = hi - lo;
-        c->grid.qmin[k]   = lo;
-        c->grid.qscale[k] = ext > 0.0f ? (ext / 65535.0f) * 1.0001f : 1.0f;  // qmin + 65535*scale >= hi
+        t.bmin[k]        = lo;
+        t.bmax[k]        = hi;
+        t.grid.qmin[k]   = lo;
+        t.grid.qscale[k] = ext > 0.0f ? (ext / 65535.0f) * 1.0001f : 1.0f;  // qmin + 65535*scale >= hi
     }
-    hipLaunchKernelGGL(k_wide_flags, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, c->lt, flags);
-    rc = device_scan(c, flags, nNodes, tileSums, total);
+    t.sceneAbs = sa;
+    hipLaunchKernelGGL(k_wide_flags, dim3(cdiv(t.nNodes, 256)), dim3(256), 0, st, t.dBuildNodes, t.nNodes, t.lt,
+                       t.dWideIdx);
+    const int rc = device_scan(c, t.dWideIdx, t.nNodes, tileSums, total);
     if(rc) { cleanup(); return rc; }
     uint32_t nInner = 0;
-    BCHK(hipMemcpyAsync(&nInner, total, 4, hipMemcpyDeviceToHost, st));
-    BCHK(hipStreamSynchronize(st));
-    if(nInner >= (1u << 26)) { cleanup(); return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^26 BVH4 nodes"); }
-    dfree(c->dNodes);
-    dfree(c->dTris);
-    BCHK(dalloc(c->dNodes, (size_t)(nInner ? nInner : 1) * 4));
-    BCHK(dalloc(c->dTris, (size_t)PRT_LEAF_SLOT_F4 * N));
-    hipLaunchKernelGGL(k_emit_wide, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, c->lt, flags,
-                       c->grid, c->dNodes);
-    hipLaunchKernelGGL(k_emit_leaves, dim3(cdiv(nNodes, 256)), dim3(256), 0, st, c->dBuildNodes, nNodes, c->dVerts, c->dIdx,
-                       c->dOrder, c->dTris);
-    BCHK(hipGetLastError());
-    BCHK(hipStreamSynchronize(st));
+    TCHK(hipMemcpyAsync(&nInner, total, 4, hipMemcpyDeviceToHost, st));
+    TCHK(hipStreamSynchronize(st));
     cleanup();
-#undef BCHK
-    c->sceneAbs = sa;
-    c->nInner   = nInner;
-    c->root     = nInner ? 0 : (int32_t) ~((0u << 3) | N);
+    t.nInner = nInner;
+    return PRT_OK;
+}
+
+// BVH4 nodes (and, for trees over triangles, the leaf records) of one tree at its place in the shared arrays
+static void tree_emit(prt_context* c, Tree& t, bool triangles)
+{
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL(k_emit_wide, dim3(cdiv(t.nNodes, 256)), dim3(256), 0, st, t.dBuildNodes, t.nNodes, t.lt,
+                       t.dWideIdx, t.grid, c->dNodes, t.nodeBase, t.slotBase);
+    if(triangles)
+        hipLaunchKernelGGL(k_emit_leaves, dim3(cdiv(t.nNodes, 256)), dim3(256), 0, st, t.dBuildNodes, t.nNodes,
+                           c->dVerts, c->dIdx + (size_t)3 * t.first, t.dOrder, c->dTris, t.slotBase);
+    t.root = t.nInner ? (int32_t)t.nodeBase : (int32_t) ~((t.slotBase << 3) | t.N);
+}
+
+static bool is_identity(const float* m)
+{
+    static const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    return memcmp(m, id, sizeof id) == 0;
+}
+static prt_host::mat4 to_mat4(const float* m)
+{
+    prt_host::mat4 r;
+    for(int cc = 0; cc < 4; ++cc)
+        for(int rr = 0; rr < 4; ++rr) r[cc][rr] = m[cc * 4 + rr];
+    return r;
+}
+
+// Top level of a two-level scene: conservative world boxes of the instances (bottom-level root box through the
+// transform, in double, rounded outwards and padded), a tree over them with one instance per leaf.
+static int tlas_build(prt_context* c)
+{
+    const size_t        n = c->instances.size();
+    std::vector<float4> boxes(2 * n);
+    double              padScale = 1.0;
+    for(size_t i = 0; i < n; ++i)
+    {
+        const prt_instance& in = c->instances[i];
+        const Tree&         b  = c->blas[in.blas];
+        const float*        M  = in.transform;
+        double              lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, amax = 0.0;
+        for(int cr = 0; cr < 8; ++cr)
+        {
+            const double p[3] = {(cr & 1) ? b.bmax[0] : b.bmin[0], (cr & 2) ? b.bmax[1] : b.bmin[1],
+                                 (cr & 4) ? b.bmax[2] : b.bmin[2]};
+            for(int k = 0; k < 3; ++k)
+            {
+                const double w = (double)M[0 + k] * p[0] + (double)M[4 + k] * p[1] + (double)M[8 + k] * p[2] + (double)M[12 + k];
+                lo[k] = w < lo[k] ? w : lo[k];
+                hi[k] = w > hi[k] ? w : hi[k];
+                amax  = fabs(w) > amax ? fabs(w) : amax;
+            }
+        }
+        // condition of the linear part (row-sum norms): scales the rounding error of o' = W*o, M*o' - o
+        double kappa = 1.0;
+        if(!is_identity(M))
+        {
+            const prt_host::mat4 W = prt_host::inverse(to_mat4(M));
+            double nM = 0.0, nW = 0.0;
+            for(int r = 0; r < 3; ++r)
+            {
+                const double rm = fabs((double)M[0 + r]) + fabs((double)M[4 + r]) + fabs((double)M[8 + r]);
+                const double rw = fabs((double)W[0][r]) + fabs((double)W[1][r]) + fabs((double)W[2][r]);
+                nM = rm > nM ? rm : nM;
+                nW = rw > nW ? rw : nW;
+            }
+            kappa = nM * nW;
+            bool finite = true;
+            for(int cc = 0; cc < 4; ++cc)
+                for(int rr = 0; rr < 4; ++rr) finite = finite && std::isfinite(W[cc][rr]);
+            if(!finite || !(kappa == kappa) || kappa > 1024.0 || !(amax < 1e30))
+                return fail(c, PRT_E_INVALID, "prt_build_accel: the transform of instance %zu is singular or too ill-conditioned (condition %g)", i, kappa);
+            if(kappa < 1.0) kappa = 1.0;
+        }
+        padScale = kappa * kappa > padScale ? kappa * kappa : padScale;
+        const double pad = 16.0 * 5.9604644775390625e-08 * kappa * amax + 1e-30;
+        for(int k = 0; k < 3; ++k)
+        {
+            ((float*)&boxes[2 * i])[k]     = nextafterf((float)(lo[k] - pad), -INFINITY);
+            ((float*)&boxes[2 * i + 1])[k] = nextafterf((float)(hi[k] + pad), INFINITY);
+        }
+        boxes[2 * i].w = boxes[2 * i + 1].w = 0.0f;
+    }
+    c->padScale = (float)padScale;
+    float4* dBoxes = nullptr;
+    HIPCHK(c, dalloc(dBoxes, 2 * n));
+    hipError_t e = hipMemcpy(dBoxes, boxes.data(), 2 * n * sizeof(float4), hipMemcpyHostToDevice);
+    int        rc = PRT_OK;
+    if(e == hipSuccess)
+    {
+        c->top.first = 0;
+        c->top.N     = (uint32_t)n;
+        rc           = tree_build(c, c->top, dBoxes, 1u, PRT_TLAS_MAX_DEPTH);
+    }
+    dfree(dBoxes);
+    HIPCHK(c, e);
+    return rc;
+}
+
+// Instance tables of a two-level scene: traversal records in top-level leaf order, shading records + primitive bases in
+// the caller's order. World -> object = glm's inverse(mat4) (host/prt_math.h), as the oracle computes it.
+static int instance_tables(prt_context* c)
+{
+    const size_t          n = c->instances.size();
+    std::vector<uint32_t> order(n), base(n + 1);
+    HIPCHK(c, hipMemcpy(order.data(), c->top.dOrder, n * 4, hipMemcpyDeviceToHost));
+    uint64_t b = 0;
+    for(size_t i = 0; i < n; ++i)
+    {
+        base[i] = (uint32_t)b;
+        b += c->blas[c->instances[i].blas].N;
+    }
+    base[n] = (uint32_t)b;
+    std::vector<float4> trav(n * PRT_INST_F4), shade(n * 8);
+    auto                bits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    for(size_t j = 0; j < n; ++j)
+    {
+        const size_t        i  = order[j];
+        const prt_instance& in = c->instances[i];
+        const Tree&         t  = c->blas[in.blas];
+        const bool          id = is_identity(in.transform);
+        const prt_host::mat4 M = to_mat4(in.transform), W = prt_host::inverse(M);
+        float4*              r = &trav[j * PRT_INST_F4];
+        for(int k = 0; k < 3; ++k) r[k] = make_float4(W[0][k], W[1][k], W[2][k], W[3][k]);
+        r[3] = make_float4(t.grid.qmin[0], t.grid.qmin[1], t.grid.qmin[2], t.sceneAbs);
+        r[4] = make_float4(t.grid.qscale[0], t.grid.qscale[1], t.grid.qscale[2], bits((uint32_t)t.root));
+        r[5] = make_float4(bits(base[i]), bits(id ? 1u : 0u), 0.0f, 0.0f);
+        r[6] = r[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float4* q = &shade[i * 8];
+        for(int k = 0; k < 3; ++k)
+        {
+            q[k]     = make_float4(M[0][k], M[1][k], M[2][k], M[3][k]);
+            q[3 + k] = make_float4(W[k][0], W[k][1], W[k][2], 0.0f);  // row k of transpose(inverse(M))
+        }
+        q[6] = make_float4(bits(t.first), bits(id ? 1u : 0u), 0.0f, 0.0f);
+        q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    dfree(c->dInst);
+    dfree(c->dShadeInst);
+    dfree(c->dInstBase);
+    HIPCHK(c, dalloc(c->dInst, trav.size()));
+    HIPCHK(c, dalloc(c->dShadeInst, shade.size()));
+    HIPCHK(c, dalloc(c->dInstBase, n + 1));
+    HIPCHK(c, hipMemcpy(c->dInst, trav.data(), trav.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dShadeInst, shade.data(), shade.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dInstBase, base.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+    return PRT_OK;
+}
+
+// Traversal layout of all trees (after a build or a refit of the bottom level): for a two-level scene this (re)builds
+// the top level from the current boxes of the bottom-level structures and the current transforms.
+static int accel_emit(prt_context* c)
+{
+    auto cleanup = [&]() {};
+    int  rc;
+    if(!c->twoLevel())
+    {
+        if((rc = tree_layout(c, c->top))) return rc;
+        if(c->top.nInner >= (1u << 26)) return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^26 BVH4 nodes");
+        c->top.nodeBase = c->top.slotBase = 0;
+        dfree(c->dNodes);
+        dfree(c->dTris);
+        TCHK(dalloc(c->dNodes, (size_t)(c->top.nInner ? c->top.nInner : 1) * 4));
+        TCHK(dalloc(c->dTris, (size_t)PRT_LEAF_SLOT_F4 * c->top.N));
+        tree_emit(c, c->top, true);
+    }
+    else
+    {
+        for(Tree& t : c->blas)
+            if((rc = tree_layout(c, t))) return rc;
+        if((rc = tlas_build(c))) return rc;
+        if((rc = tree_layout(c, c->top))) return rc;
+        uint64_t nb = c->top.nInner, sb = 0;
+        c->top.nodeBase = c->top.slotBase = 0;
+        for(Tree& t : c->blas)
+        {
+            t.nodeBase = (uint32_t)nb;
+            t.slotBase = (uint32_t)sb;
+            nb += t.nInner;
+            sb += t.N;
+        }
+        if(nb >= (1u << 26) || sb >= (1u << 28)) return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^26 BVH4 nodes");
+        dfree(c->dNodes);
+        dfree(c->dTris);
+        TCHK(dalloc(c->dNodes, (size_t)(nb ? nb : 1) * 4));
+        TCHK(dalloc(c->dTris, (size_t)PRT_LEAF_SLOT_F4 * sb));
+        tree_emit(c, c->top, false);
+        for(Tree& t : c->blas) tree_emit(c, t, true);
+        TCHK(hipGetLastError());
+        TCHK(hipStreamSynchronize(c->stream));
+        if((rc = instance_tables(c))) return rc;
+    }
+    TCHK(hipGetLastError());
+    TCHK(hipStreamSynchronize(c->stream));
+    dfree(c->top.dWideIdx);
+    for(Tree& t : c->blas) dfree(t.dWideIdx);
+    return PRT_OK;
+}
+#undef TCHK
+
+int prt_set_instances(prt_context* c, const prt_blas_range* blas, size_t nblas, const prt_instance* inst, size_t ninst)
+{
+    if(!c) return PRT_E_INVALID;
+    if(!c->haveScene) return fail(c, PRT_E_NOSCENE, "prt_set_instances: no scene");
+    if(ninst && (!blas || !inst || nblas == 0)) return fail(c, PRT_E_INVALID, "prt_set_instances: null input");
+    if(ninst >= (1u << 24) || nblas >= (1u << 24)) return fail(c, PRT_E_LIMIT, "prt_set_instances: more than 2^24 instances");
+    uint64_t total = 0;
+    for(size_t k = 0; k < (ninst ? nblas : 0); ++k)
+        if(blas[k].n_triangles == 0 || (uint64_t)blas[k].first_triangle + blas[k].n_triangles > c->ntri)
+            return fail(c, PRT_E_INVALID, "prt_set_instances: range %zu (%u + %u) outside the scene's %u triangles", k,
+                        blas[k].first_triangle, blas[k].n_triangles, c->ntri);
+    for(size_t i = 0; i < ninst; ++i)
+    {
+        if(inst[i].blas >= nblas) return fail(c, PRT_E_INVALID, "prt_set_instances: instance %zu names structure %u of %zu", i, inst[i].blas, nblas);
+        const float* m = inst[i].transform;
+        if(m[3] != 0.0f || m[7] != 0.0f || m[11] != 0.0f || m[15] != 1.0f)
+            return fail(c, PRT_E_INVALID, "prt_set_instances: instance %zu: the fourth row of the transform must be (0,0,0,1)", i);
+        total += blas[inst[i].blas].n_triangles;
+    }
+    if(total >= 0xffffffffull) return fail(c, PRT_E_LIMIT, "prt_set_instances: more than 2^32 - 2 instanced triangles");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, sync_all(c));
+    free_accel(c);
+    c->blasRanges.assign(blas, blas + (ninst ? nblas : 0));
+    c->instances.assign(inst, inst + ninst);
     return PRT_OK;
 }
 
@@ -562,115 +918,50 @@ int prt_build_accel(prt_context* c)
     if(!c->haveScene) return fail(c, PRT_E_NOSCENE, "prt_build_accel: no scene");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, sync_all(c));
-    const auto     t0 = std::chrono::steady_clock::now();
-    const uint32_t N  = c->ntri;
-    hipStream_t    st = c->stream;
-    dfree(c->dBuildNodes);
-    dfree(c->dOrder);
-    dfree(c->dNodes);
-    dfree(c->dTris);
-    c->haveAccel = false;
-
-    const uint32_t maxSplit = N / (kLeafMax + 1) + 1;
-    uint32_t *     order2 = nullptr, *nodeOf = nullptr, *nodeOf2 = nullptr, *cb = nullptr, *bins = nullptr;
-    uint32_t *     flags = nullptr, *scanBuf = nullptr, *tileSums = nullptr, *rank = nullptr, *splitOf = nullptr;
-    uint32_t*      total = nullptr;
-    float4*        pbox  = nullptr;
-    SplitRec*      splits = nullptr;
-    int            rc     = PRT_OK;
-    auto           cleanup = [&]() {
-        dfree(order2); dfree(nodeOf); dfree(nodeOf2); dfree(cb); dfree(bins); dfree(flags); dfree(scanBuf);
-        dfree(tileSums); dfree(rank); dfree(splitOf); dfree(total); dfree(pbox); dfree(splits);
-    };
-#define BCHK(expr)                                                                                        \
-    do                                                                                                    \
-    {                                                                                                     \
-        hipError_t e_ = (expr);                                                                           \
-        if(e_ != hipSuccess)                                                                              \
-        {                                                                                                 \
-            cleanup();                                                                                    \
-            return fail(c, PRT_E_HIP, "prt_build_accel: %s failed: %s", #expr, hipGetErrorString(e_));    \
-        }                                                                                                 \
-    } while(0)
-    BCHK(dalloc(c->dBuildNodes, (size_t)2 * N));
-    BCHK(dalloc(c->dOrder, (size_t)N));
-    BCHK(dalloc(order2, (size_t)N));
-    BCHK(dalloc(nodeOf, (size_t)N));
-    BCHK(dalloc(nodeOf2, (size_t)N));
-    BCHK(dalloc(cb, (size_t)12 * N));
-    BCHK(dalloc(bins, (size_t)maxSplit * kBinWords));
-    BCHK(dalloc(flags, (size_t)2 * N));
-    BCHK(dalloc(scanBuf, (size_t)2 * N));
-    BCHK(dalloc(tileSums, (size_t)cdiv((size_t)2 * N, PRT_SCAN_TILE) + 1));
-    BCHK(dalloc(rank, (size_t)N));
-    BCHK(dalloc(splitOf, (size_t)N));
-    BCHK(dalloc(total, (size_t)1));
-    BCHK(dalloc(pbox, (size_t)2 * N));
-    BCHK(dalloc(splits, (size_t)maxSplit));
-
-    uint32_t* orderCur = c->dOrder;
-    uint32_t* orderAlt = order2;
-    hipLaunchKernelGGL(k_build_reset, dim3(1), dim3(64), 0, st, c->dBuildNodes, cb, N);
-    hipLaunchKernelGGL(k_prim_boxes, dim3(cdiv(N, 256)), dim3(256), 0, st, c->dVerts, c->dIdx, N, pbox, orderCur,
-                       nodeOf, c->dBuildNodes, cb);
-    uint32_t   levelStart = 0, levelCount = 1, nNodes = 1, depth = 1;
-    LevelTable lt;
-    memset(&lt, 0, sizeof lt);
-    for(;;)
+    const auto t0 = std::chrono::steady_clock::now();
+    free_accel(c);
+    int rc = PRT_OK;
+    if(!c->twoLevel())
     {
-        lt.start[lt.n++] = levelStart;
-        hipLaunchKernelGGL(k_level_flags, dim3(cdiv(levelCount, 256)), dim3(256), 0, st, c->dBuildNodes, levelStart,
-                           levelCount, rank);
-        rc = device_scan(c, rank, levelCount, tileSums, total);
-        if(rc) { cleanup(); return rc; }
-        uint32_t nsplit = 0;
-        BCHK(hipMemcpyAsync(&nsplit, total, 4, hipMemcpyDeviceToHost, st));
-        BCHK(hipStreamSynchronize(st));
-        if(nsplit == 0) break;
-        if(nsplit > maxSplit) { cleanup(); return fail(c, PRT_E_LIMIT, "prt_build_accel: split overflow"); }
-        hipLaunchKernelGGL(k_level_prepare, dim3(cdiv(levelCount, 256)), dim3(256), 0, st, c->dBuildNodes, levelStart,
-                           levelCount, rank, splits);
-        hipLaunchKernelGGL(k_split_of, dim3(cdiv(levelCount, 256)), dim3(256), 0, st, c->dBuildNodes, levelStart,
-                           levelCount, rank, splitOf);
-        hipLaunchKernelGGL(k_clear_bins, dim3(cdiv((size_t)nsplit * kBinWords, 256)), dim3(256), 0, st, bins, nsplit);
-        hipLaunchKernelGGL(k_bin, dim3(cdiv(N, 256)), dim3(256), 0, st, orderCur, nodeOf, c->dBuildNodes, cb, pbox,
-                           rank, levelStart, N, bins);
-        hipLaunchKernelGGL(k_split, dim3(cdiv(nsplit, 64)), dim3(64), 0, st, c->dBuildNodes, cb, bins, splits, nsplit,
-                           nNodes);
-        hipLaunchKernelGGL(k_flags, dim3(cdiv(N, 256)), dim3(256), 0, st, orderCur, nodeOf, splitOf, splits,
-                           c->dBuildNodes, pbox, levelStart, N, flags, scanBuf);
-        rc = device_scan(c, scanBuf, N, tileSums, total);
-        if(rc) { cleanup(); return rc; }
-        hipLaunchKernelGGL(k_scatter, dim3(cdiv(N, 256)), dim3(256), 0, st, orderCur, nodeOf, splitOf, splits,
-                           c->dBuildNodes, cb, pbox, flags, scanBuf, levelStart, N, orderAlt, nodeOf2);
-        BCHK(hipGetLastError());
-        std::swap(orderCur, orderAlt);
-        std::swap(nodeOf, nodeOf2);
-        levelStart = nNodes;
-        levelCount = 2 * nsplit;
-        nNodes += 2 * nsplit;
-        depth++;
-        if(depth > PRT_MAX_DEPTH)
+        c->top.first = 0;
+        c->top.N     = c->ntri;
+        rc           = tree_build(c, c->top, nullptr, kLeafMax, PRT_MAX_DEPTH);
+    }
+    else
+    {
+        c->blas.resize(c->blasRanges.size());
+        for(size_t k = 0; k < c->blas.size() && rc == PRT_OK; ++k)
         {
-            cleanup();
-            return fail(c, PRT_E_LIMIT, "prt_build_accel: tree deeper than %d levels", PRT_MAX_DEPTH);
+            c->blas[k].first = c->blasRanges[k].first_triangle;
+            c->blas[k].N     = c->blasRanges[k].n_triangles;
+            rc               = tree_build(c, c->blas[k], nullptr, kLeafMax, PRT_MAX_DEPTH);
         }
     }
-    if(orderCur != c->dOrder)
-        BCHK(hipMemcpyAsync(c->dOrder, orderCur, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
-
-    BCHK(hipGetLastError());
-    BCHK(hipStreamSynchronize(st));
-    cleanup();
-#undef BCHK
-    c->lt     = lt;
-    c->nNodes = nNodes;
-    c->depth  = depth;
-    rc        = emit_layout(c);
-    if(rc) return rc;
+    if(rc == PRT_OK) rc = accel_emit(c);
+    if(rc)
+    {
+        const std::string msg = c->err;
+        free_accel(c);
+        c->err = msg;
+        return rc;
+    }
     c->haveAccel  = true;
     c->accelStale = false;
     c->buildMs    = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if(c->twoLevel() && c->gridTwo[0] == 0)
+    {
+        auto resident = [&](const void* fn) -> uint32_t {
+            int nb = 0;
+            if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, PRT_TRACE_BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
+            return (uint32_t)nb * (uint32_t)c->numCU;
+        };
+        c->gridTwo[0] = resident((const void*)k_extend<false, true>);
+        c->gridTwo[1] = resident((const void*)k_shadow<false, true>);
+        c->gridTwo[2] = resident((const void*)k_trace_batch<false, true>);
+        c->gridTwo[3] = resident((const void*)k_ao_shade<true>);
+        c->gridTwo[4] = resident((const void*)k_shadow_extend<false, true>);
+        c->gridTwo[5] = resident((const void*)k_shade<true>);
+    }
     return PRT_OK;
 }
 
@@ -693,6 +984,21 @@ int prt_update_vertices(prt_context* c, const prt_vertex* v, size_t nv)
     return PRT_OK;
 }
 
+// boxes of one tree over triangles from the current vertices: leaves first, then level by level from the deepest one
+static void tree_refit(prt_context* c, Tree& t)
+{
+    hipLaunchKernelGGL(k_refit_leaves, dim3(cdiv(t.nNodes, 256)), dim3(256), 0, c->stream, t.dBuildNodes, t.nNodes,
+                       c->dVerts, c->dIdx + (size_t)3 * t.first, t.dOrder);
+    for(uint32_t l = t.lt.n; l-- > 0;)
+    {
+        const uint32_t start = t.lt.start[l];
+        const uint32_t end   = l + 1 < t.lt.n ? t.lt.start[l + 1] : t.nNodes;
+        if(end > start)
+            hipLaunchKernelGGL(k_refit_level, dim3(cdiv(end - start, 256)), dim3(256), 0, c->stream, t.dBuildNodes, start,
+                               end - start);
+    }
+}
+
 int prt_refit_accel(prt_context* c)
 {
     if(!c) return PRT_E_INVALID;
@@ -700,21 +1006,45 @@ int prt_refit_accel(prt_context* c)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, sync_all(c));
     const auto t0 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(k_refit_leaves, dim3(cdiv(c->nNodes, 256)), dim3(256), 0, c->stream, c->dBuildNodes, c->nNodes,
-                       c->dVerts, c->dIdx, c->dOrder);
-    for(uint32_t l = c->lt.n; l-- > 0;)
-    {
-        const uint32_t start = c->lt.start[l];
-        const uint32_t end   = l + 1 < c->lt.n ? c->lt.start[l + 1] : c->nNodes;
-        if(end > start)
-            hipLaunchKernelGGL(k_refit_level, dim3(cdiv(end - start, 256)), dim3(256), 0, c->stream, c->dBuildNodes,
-                               start, end - start);
-    }
+    if(!c->twoLevel())
+        tree_refit(c, c->top);
+    else
+        for(Tree& t : c->blas) tree_refit(c, t);  // the top level is rebuilt from the new boxes by accel_emit
     HIPCHK(c, hipGetLastError());
-    const int rc = emit_layout(c);
+    const int rc = accel_emit(c);
     if(rc) return rc;
     c->accelStale = false;
     c->refitMs    = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PRT_OK;
+}
+
+// The "updateOnly" path of the top level (vkRT_TLAS.cpp:178-279 with updateOnly = true): new transforms for the
+// instances of prt_set_instances (n_instances x 16 floats, column-major); the bottom-level structures stay.
+int prt_update_instance_transforms(prt_context* c, const float* transforms, size_t ninst)
+{
+    if(!c) return PRT_E_INVALID;
+    if(!c->twoLevel()) return fail(c, PRT_E_INVALID, "prt_update_instance_transforms: the scene has no instances");
+    if(!transforms || ninst != c->instances.size())
+        return fail(c, PRT_E_INVALID, "prt_update_instance_transforms: %zu transforms given, the scene has %zu instances",
+                    ninst, c->instances.size());
+    for(size_t i = 0; i < ninst; ++i)
+    {
+        const float* m = transforms + 16 * i;
+        if(m[3] != 0.0f || m[7] != 0.0f || m[11] != 0.0f || m[15] != 1.0f)
+            return fail(c, PRT_E_INVALID, "prt_update_instance_transforms: instance %zu: the fourth row of the transform must be (0,0,0,1)", i);
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, sync_all(c));
+    for(size_t i = 0; i < ninst; ++i) memcpy(c->instances[i].transform, transforms + 16 * i, 64);
+    if(!c->haveAccel) return PRT_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int  rc = accel_emit(c);
+    if(rc)
+    {
+        c->haveAccel = false;
+        return rc;
+    }
+    c->refitMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PRT_OK;
 }
 
@@ -818,13 +1148,15 @@ static void fill_bvh_view(const prt_context* c, BvhView& b)
 {
     b.nodes    = c->dNodes;
     b.tris     = c->dTris;
-    b.root     = c->root;
-    b.sceneAbs = c->sceneAbs;
+    b.root     = c->top.root;
+    b.sceneAbs = c->top.sceneAbs;
     for(int k = 0; k < 3; ++k)
     {
-        b.qmin[k]   = c->grid.qmin[k];
-        b.qscale[k] = c->grid.qscale[k];
+        b.qmin[k]   = c->top.grid.qmin[k];
+        b.qscale[k] = c->top.grid.qscale[k];
     }
+    b.inst     = c->dInst;
+    b.padScale = c->padScale;
 }
 
 static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& f, uint32_t nsub = 1, uint32_t iterStride = 1)
@@ -841,6 +1173,9 @@ static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& 
     sc.ntex         = c->ntex;
     sc.seed         = c->seed;
     sc.ntri         = c->ntri;
+    sc.shadeInst    = c->dShadeInst;
+    sc.instBase     = c->dInstBase;
+    sc.ninst        = (uint32_t)c->instances.size();
     fill_bvh_view(c, sc.bvh);
     f.w       = c->w;
     f.h       = c->h;
@@ -865,7 +1200,16 @@ static void launch_extend(prt_context* c, hipStream_t st, const SceneView& sc, c
                           uint32_t q /* generation of path state */, const uint32_t* n, uint32_t* work, uint32_t primary)
 {
     ProfScope ps(c, PRT_K_EXTEND, st);
-    if(c->profLevel >= 2)
+    if(c->twoLevel())
+    {
+        if(c->profLevel >= 2)
+            hipLaunchKernelGGL((k_extend<true, true>), dim3(c->gridTwo[0]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, q, n, work,
+                               primary, trace_tune());
+        else
+            hipLaunchKernelGGL((k_extend<false, true>), dim3(c->gridTwo[0]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, q, n, work,
+                               primary, trace_tune());
+    }
+    else if(c->profLevel >= 2)
         hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, q, n, work, primary,
                            trace_tune());
     else
@@ -890,8 +1234,12 @@ static int render_ao(prt_context* c)
     launch_extend(c, st, sc, f, c->gridExtend, 0u, nullptr, p.counters + 0, 1u);
     {
         ProfScope ps(c, PRT_K_AO_SHADE, st);
-        hipLaunchKernelGGL(k_ao_shade, dim3(c->gridAo), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo, c->flags,
-                           p.counters + 1);
+        if(c->twoLevel())
+            hipLaunchKernelGGL(k_ao_shade<true>, dim3(c->gridTwo[3]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo, c->flags,
+                               p.counters + 1);
+        else
+            hipLaunchKernelGGL(k_ao_shade<false>, dim3(c->gridAo), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo, c->flags,
+                               p.counters + 1);
     }
     HIPCHK(c, hipGetLastError());
     c->lastPipe = 0;
@@ -958,13 +1306,28 @@ static int render_path_pass(prt_context* c, int pi, int aa, uint32_t nsub = 1, u
         if(b == 0 || !c->fuse) launch_extend(c, st, sc, f, c->gridExtend, (uint32_t)b, nIn, p.counters + 64 + b, b == 0 ? 1u : 0u);
         {
             ProfScope ps(c, PRT_K_SHADE, st);
-            hipLaunchKernelGGL(k_shade, dim3(gridShade), dim3(256), 0, st, sc, f, c->ubo, fl, (uint32_t)b, nIn,
-                               p.counters + b + 1, p.counters + 32 + b);
+            if(c->twoLevel())
+                hipLaunchKernelGGL(k_shade<true>, dim3(c->gridTwo[5]), dim3(256), 0, st, sc, f, c->ubo, fl, (uint32_t)b, nIn,
+                                   p.counters + b + 1, p.counters + 32 + b);
+            else
+                hipLaunchKernelGGL(k_shade<false>, dim3(gridShade), dim3(256), 0, st, sc, f, c->ubo, fl, (uint32_t)b, nIn,
+                                   p.counters + b + 1, p.counters + 32 + b);
         }
         if(c->fuse && b < B)
         {
             ProfScope ps(c, PRT_K_SHADOW_EXTEND, st);
-            if(c->profLevel >= 2)
+            if(c->twoLevel())
+            {
+                if(c->profLevel >= 2)
+                    hipLaunchKernelGGL((k_shadow_extend<true, true>), dim3(c->gridTwo[4]), dim3(PRT_TRACE_BLOCK), 0, st, sc,
+                                       f, (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
+                                       (const uint32_t*)(p.counters + b + 1), p.counters + 64 + b + 1, trace_tune());
+                else
+                    hipLaunchKernelGGL((k_shadow_extend<false, true>), dim3(c->gridTwo[4]), dim3(PRT_TRACE_BLOCK), 0, st, sc,
+                                       f, (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
+                                       (const uint32_t*)(p.counters + b + 1), p.counters + 64 + b + 1, trace_tune());
+            }
+            else if(c->profLevel >= 2)
                 hipLaunchKernelGGL(k_shadow_extend<true>, dim3(c->gridFused), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
                                    (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
                                    (const uint32_t*)(p.counters + b + 1), p.counters + 64 + b + 1, trace_tune());
@@ -976,7 +1339,18 @@ static int render_path_pass(prt_context* c, int pi, int aa, uint32_t nsub = 1, u
         else
         {
             ProfScope ps(c, PRT_K_SHADOW, st);
-            if(c->profLevel >= 2)
+            if(c->twoLevel())
+            {
+                if(c->profLevel >= 2)
+                    hipLaunchKernelGGL((k_shadow<true, true>), dim3(c->gridTwo[1]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+                                       (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
+                                       trace_tune());
+                else
+                    hipLaunchKernelGGL((k_shadow<false, true>), dim3(c->gridTwo[1]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
+                                       (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
+                                       trace_tune());
+            }
+            else if(c->profLevel >= 2)
                 hipLaunchKernelGGL(k_shadow<true>, dim3(c->gridShadow), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
                                    (const uint32_t*)(p.counters + 32 + b),
                                    p.counters + 128 + b, (uint32_t)b, trace_tune());
@@ -1186,9 +1560,19 @@ int prt_get_stats(prt_context* c, prt_stats* s)
     HIPCHK(c, hipMemcpy(&overruns, c->stats + 28, 8, hipMemcpyDeviceToHost));
     s->rays            = rays[0] + rays[1];
     s->iterations      = c->iterations;
-    s->bvh_nodes       = c->nNodes;
-    s->bvh_inner_nodes = c->nInner;
-    s->bvh_depth       = c->depth;
+    s->bvh_nodes       = c->top.nNodes;
+    s->bvh_inner_nodes = c->top.nInner;
+    s->bvh_depth       = c->top.depth;
+    {
+        uint32_t deepest = 0;
+        for(const Tree& t : c->blas)  // two-level scenes: all structures; depth = top level + deepest bottom level
+        {
+            s->bvh_nodes += t.nNodes;
+            s->bvh_inner_nodes += t.nInner;
+            deepest = t.depth > deepest ? t.depth : deepest;
+        }
+        s->bvh_depth += deepest;
+    }
     s->bvh_build_ms    = c->buildMs;
     s->bvh_refit_ms    = c->refitMs;
     s->trace_overruns  = (uint32_t)(overruns > 0xffffffffull ? 0xffffffffull : overruns);
@@ -1266,6 +1650,26 @@ int prt_get_profile(prt_context* c, prt_profile* out)
     return PRT_OK;
 }
 
+static void launch_trace_batch(prt_context* c, hipStream_t st, const BvhView& bvh, const void* rays, size_t n, int any,
+                               void* hits, uint32_t* work)
+{
+    if(c->twoLevel())
+    {
+        if(any)
+            hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(c->gridTwo[2]), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
+                               (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
+        else
+            hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(c->gridTwo[2]), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
+                               (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
+    }
+    else if(any)
+        hipLaunchKernelGGL(k_trace_batch<true>, dim3(c->gridBatch), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
+                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
+    else
+        hipLaunchKernelGGL(k_trace_batch<false>, dim3(c->gridBatch), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
+                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
+}
+
 int prt_trace_device(prt_context* c, const void* rays, size_t n, int any, void* hits, float* ms)
 {
     if(!c || !rays || !hits) return PRT_E_INVALID;
@@ -1281,15 +1685,9 @@ int prt_trace_device(prt_context* c, const void* rays, size_t n, int any, void* 
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
     uint32_t*      work = c->batchCounter;  // work-fetch cursor of this launch
-    const uint32_t grid = c->gridBatch;
     HIPCHK(c, hipMemsetAsync(work, 0, 4, c->stream));
     HIPCHK(c, hipEventRecord(e0, c->stream));
-    if(any)
-        hipLaunchKernelGGL(k_trace_batch<true>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc.bvh,
-                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
-    else
-        hipLaunchKernelGGL(k_trace_batch<false>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, c->stream, sc.bvh,
-                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
+    launch_trace_batch(c, c->stream, sc.bvh, rays, n, any, hits, work);
     hipError_t e = hipGetLastError();
     if(e == hipSuccess) e = hipEventRecord(e1, c->stream);
     if(e == hipSuccess) e = hipEventSynchronize(e1);
@@ -1323,12 +1721,7 @@ int prt_trace_device_noalloc(prt_context* c, const void* rays, size_t n, int any
     fill_bvh_view(c, bvh);
     // the array keeps the last call's cursor: it must start at zero
     HIPCHK(c, hipMemsetAsync(work, 0, PRT_NOALLOC_SCRATCH_BYTES, st));
-    if(any)
-        hipLaunchKernelGGL(k_trace_batch<true>, dim3(c->gridBatch), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
-                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
-    else
-        hipLaunchKernelGGL(k_trace_batch<false>, dim3(c->gridBatch), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
-                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
+    launch_trace_batch(c, st, bvh, rays, n, any, hits, work);
     HIPCHK(c, hipGetLastError());
     return PRT_OK;
 }
@@ -1352,24 +1745,38 @@ int prt_trace(prt_context* c, const prt_ray* rays, size_t n, int any, prt_hit* o
     return PRT_OK;
 }
 
-int prt_read_bvh(prt_context* c, prt_bvh_node* nodes, uint32_t* order)
+static int read_tree(prt_context* c, const Tree& t, prt_bvh_node* nodes, uint32_t* order)
 {
-    if(!c) return PRT_E_INVALID;
-    if(!c->haveAccel) return fail(c, PRT_E_NOSCENE, "prt_read_bvh: no acceleration structure");
     HIPCHK(c, hipSetDevice(c->device));
     if(nodes)
     {
         float4* d = nullptr;
-        HIPCHK(c, dalloc(d, (size_t)2 * c->nNodes));
-        hipLaunchKernelGGL(k_decode_nodes, dim3(cdiv(c->nNodes, 256)), dim3(256), 0, c->stream, c->dBuildNodes,
-                           c->nNodes, d);
-        hipError_t e = hipMemcpyAsync(nodes, d, (size_t)c->nNodes * 32, hipMemcpyDeviceToHost, c->stream);
+        HIPCHK(c, dalloc(d, (size_t)2 * t.nNodes));
+        hipLaunchKernelGGL(k_decode_nodes, dim3(cdiv(t.nNodes, 256)), dim3(256), 0, c->stream, t.dBuildNodes, t.nNodes, d);
+        hipError_t e = hipMemcpyAsync(nodes, d, (size_t)t.nNodes * 32, hipMemcpyDeviceToHost, c->stream);
         if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
         dfree(d);
         HIPCHK(c, e);
     }
-    if(order) HIPCHK(c, hipMemcpy(order, c->dOrder, (size_t)c->ntri * 4, hipMemcpyDeviceToHost));
+    if(order) HIPCHK(c, hipMemcpy(order, t.dOrder, (size_t)t.N * 4, hipMemcpyDeviceToHost));
     return PRT_OK;
+}
+
+int prt_read_bvh(prt_context* c, prt_bvh_node* nodes, uint32_t* order)
+{
+    if(!c) return PRT_E_INVALID;
+    if(!c->haveAccel) return fail(c, PRT_E_NOSCENE, "prt_read_bvh: no acceleration structure");
+    if(c->twoLevel()) return fail(c, PRT_E_INVALID, "prt_read_bvh: two-level scene, use prt_read_blas_bvh");
+    return read_tree(c, c->top, nodes, order);
+}
+
+int prt_read_blas_bvh(prt_context* c, uint32_t k, prt_bvh_node* nodes, uint32_t* order, uint32_t* nNodes)
+{
+    if(!c) return PRT_E_INVALID;
+    if(!c->haveAccel) return fail(c, PRT_E_NOSCENE, "prt_read_blas_bvh: no acceleration structure");
+    if(k >= c->blas.size()) return fail(c, PRT_E_INVALID, "prt_read_blas_bvh: structure %u of %zu", k, c->blas.size());
+    if(nNodes) *nNodes = c->blas[k].nNodes;
+    return read_tree(c, c->blas[k], nodes, order);
 }
 
 // measurement builds (-DPRT_SHADE_STAMPS): the raw statistics words

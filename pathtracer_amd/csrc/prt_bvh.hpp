@@ -153,27 +153,36 @@ __global__ void k_build_reset(BuildNode* nodes, uint32_t* cb, uint32_t ntri)
     }
 }
 
-// per-triangle box (exact min/max of the three vertices), identity order, root bounds
+// per-primitive box (triangles: exact min/max of the three vertices; `given` != nullptr: the boxes of the top level's
+// instances, 2 x float4 each, as they are), identity order, root bounds
 __global__ void __launch_bounds__(256) k_prim_boxes(const prt_vertex* __restrict__ verts,
                                                     const uint32_t* __restrict__ idx, uint32_t ntri,
                                                     float4* __restrict__ pbox, uint32_t* __restrict__ order,
-                                                    uint32_t* __restrict__ nodeOf, BuildNode* nodes, uint32_t* cb)
+                                                    uint32_t* __restrict__ nodeOf, BuildNode* nodes, uint32_t* cb,
+                                                    const float4* __restrict__ given)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       kmn[3] = {kKeyPosInf, kKeyPosInf, kKeyPosInf}, kmx[3] = {kKeyNegInf, kKeyNegInf, kKeyNegInf};
     uint32_t       cmn[3] = {kKeyPosInf, kKeyPosInf, kKeyPosInf}, cmx[3] = {kKeyNegInf, kKeyNegInf, kKeyNegInf};
     if(i < ntri)
     {
-        for(int k = 0; k < 3; ++k)
+        if(given)
         {
-            const float* p = verts[idx[3 * i + k]].p;
-            for(int a = 0; a < 3; ++a)
-            {
-                const uint32_t key = fkey(p[a]);
-                kmn[a]             = min(kmn[a], key);
-                kmx[a]             = max(kmx[a], key);
-            }
+            const float4 lo = given[2 * i], hi = given[2 * i + 1];
+            kmn[0] = fkey(lo.x); kmn[1] = fkey(lo.y); kmn[2] = fkey(lo.z);
+            kmx[0] = fkey(hi.x); kmx[1] = fkey(hi.y); kmx[2] = fkey(hi.z);
         }
+        else
+            for(int k = 0; k < 3; ++k)
+            {
+                const float* p = verts[idx[3 * i + k]].p;
+                for(int a = 0; a < 3; ++a)
+                {
+                    const uint32_t key = fkey(p[a]);
+                    kmn[a]             = min(kmn[a], key);
+                    kmx[a]             = max(kmx[a], key);
+                }
+            }
         const float mn[3] = {fdec(kmn[0]), fdec(kmn[1]), fdec(kmn[2])};
         const float mx[3] = {fdec(kmx[0]), fdec(kmx[1]), fdec(kmx[2])};
         pbox[2 * i]       = make_float4(mn[0], mn[1], mn[2], 0.0f);
@@ -208,20 +217,21 @@ __global__ void __launch_bounds__(256) k_prim_boxes(const prt_vertex* __restrict
 }
 
 // flags[j] = 1 when node levelStart+j must be split
+// leafMax: PRT_LEAF_MAX for triangles; 1 for the top level of a two-level scene (one instance per leaf)
 __global__ void __launch_bounds__(256) k_level_flags(const BuildNode* __restrict__ nodes, uint32_t levelStart,
-                                                     uint32_t levelCount, uint32_t* __restrict__ flags)
+                                                     uint32_t levelCount, uint32_t* __restrict__ flags, uint32_t leafMax)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j < levelCount) flags[j] = nodes[levelStart + j].count > kLeafMax ? 1u : 0u;
+    if(j < levelCount) flags[j] = nodes[levelStart + j].count > leafMax ? 1u : 0u;
 }
 
 // after the scan: rank[j] valid for splitting nodes; record node id per split, clear the bins
 __global__ void __launch_bounds__(256) k_level_prepare(const BuildNode* __restrict__ nodes, uint32_t levelStart,
                                                        uint32_t levelCount, const uint32_t* __restrict__ rank,
-                                                       SplitRec* __restrict__ splits)
+                                                       SplitRec* __restrict__ splits, uint32_t leafMax)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j < levelCount && nodes[levelStart + j].count > kLeafMax) splits[rank[j]].node = levelStart + j;
+    if(j < levelCount && nodes[levelStart + j].count > leafMax) splits[rank[j]].node = levelStart + j;
 }
 __global__ void __launch_bounds__(256) k_clear_bins(uint32_t* __restrict__ bins, uint32_t nsplit)
 {
@@ -239,7 +249,8 @@ __global__ void __launch_bounds__(256) k_clear_bins(uint32_t* __restrict__ bins,
 __global__ void __launch_bounds__(256) k_bin(const uint32_t* __restrict__ order, const uint32_t* __restrict__ nodeOf,
                                              const BuildNode* __restrict__ nodes, const uint32_t* __restrict__ cb,
                                              const float4* __restrict__ pbox, const uint32_t* __restrict__ rank,
-                                             uint32_t levelStart, uint32_t ntri, uint32_t* __restrict__ bins)
+                                             uint32_t levelStart, uint32_t ntri, uint32_t* __restrict__ bins,
+                                             uint32_t leafMax)
 {
     __shared__ uint32_t lbins[kBinWords];
     const uint32_t      i     = blockIdx.x * blockDim.x + threadIdx.x;
@@ -249,7 +260,7 @@ __global__ void __launch_bounds__(256) k_bin(const uint32_t* __restrict__ order,
     const bool          uniform = n0 == nodeOf[last];  // block-uniform: sorted by node
     if(uniform)
     {
-        if(nodes[n0].count <= kLeafMax) return;  // the whole block sits in a finished leaf
+        if(nodes[n0].count <= leafMax) return;  // the whole block sits in a finished leaf
         for(uint32_t w = threadIdx.x; w < kBinWords; w += blockDim.x)
             lbins[w] = w < 3 * kBins ? 0u : (w < 3 * kBins * 4 ? kKeyPosInf : kKeyNegInf);
         __syncthreads();
@@ -257,7 +268,7 @@ __global__ void __launch_bounds__(256) k_bin(const uint32_t* __restrict__ order,
     if(i < ntri)
     {
         const uint32_t ni = nodeOf[i];
-        if(nodes[ni].count > kLeafMax)
+        if(nodes[ni].count > leafMax)
         {
             const uint32_t p  = order[i];
             const float4   mn = pbox[2 * p], mx = pbox[2 * p + 1];
@@ -444,10 +455,10 @@ __global__ void __launch_bounds__(64) k_split(BuildNode* __restrict__ nodes, uin
 // identify splitting nodes through `splitOf` (rank per level node, ~0u for leaves) captured before.
 __global__ void __launch_bounds__(256) k_split_of(const BuildNode* __restrict__ nodes, uint32_t levelStart,
                                                   uint32_t levelCount, const uint32_t* __restrict__ rank,
-                                                  uint32_t* __restrict__ splitOf)
+                                                  uint32_t* __restrict__ splitOf, uint32_t leafMax)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j < levelCount) splitOf[j] = nodes[levelStart + j].count > kLeafMax ? rank[j] : 0xffffffffu;
+    if(j < levelCount) splitOf[j] = nodes[levelStart + j].count > leafMax ? rank[j] : 0xffffffffu;
 }
 
 __global__ void __launch_bounds__(256) k_flags(const uint32_t* __restrict__ order, const uint32_t* __restrict__ nodeOf,
@@ -633,9 +644,11 @@ PRT_DEV uint32_t quant_ceil(float v, float qmin, float scale)
     while(q < 65535.0 && (double)qmin + q * (double)scale < (double)v) q += 1.0;
     return (uint32_t)q;
 }
+// nodeBase / slotBase: position of this structure in the node / leaf arrays that the structures of a two-level scene
+// share (0 for a single-level scene); child references are absolute
 __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__ nodes, uint32_t nnodes,
                                                    LevelTable lt, const uint32_t* __restrict__ wideIdx, QuantGrid g,
-                                                   uint4* __restrict__ out)
+                                                   uint4* __restrict__ out, uint32_t nodeBase, uint32_t slotBase)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= nnodes || nodes[i].count != 0 || (level_of(lt, i) & 1u) != 0u) return;
@@ -663,7 +676,7 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
                 qmn[k][j] = quant_floor(fdec(c.bmin[k]), g.qmin[k], g.qscale[k]);
                 qmx[k][j] = quant_ceil(fdec(c.bmax[k]), g.qmin[k], g.qscale[k]);
             }
-            ref[j] = c.count == 0 ? (int32_t)wideIdx[slot[j]] : (int32_t)~((c.first << 3) | c.count);
+            ref[j] = c.count == 0 ? (int32_t)(wideIdx[slot[j]] + nodeBase) : (int32_t)~(((c.first + slotBase) << 3) | c.count);
         }
         else
         {
@@ -676,7 +689,7 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
             ref[j] = -1;
         }
     }
-    uint4* o = out + (size_t)wideIdx[i] * 4;
+    uint4* o = out + (size_t)(wideIdx[i] + nodeBase) * 4;
     for(int k = 0; k < 3; ++k)
         o[k] = make_uint4(qmn[k][0] | (qmn[k][1] << 16), qmn[k][2] | (qmn[k][3] << 16), qmx[k][0] | (qmx[k][1] << 16),
                           qmx[k][2] | (qmx[k][3] << 16));
@@ -691,13 +704,14 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
 __global__ void __launch_bounds__(256) k_emit_leaves(const BuildNode* __restrict__ nodes, uint32_t nnodes,
                                                      const prt_vertex* __restrict__ verts,
                                                      const uint32_t* __restrict__ idx,
-                                                     const uint32_t* __restrict__ order, float4* __restrict__ tris)
+                                                     const uint32_t* __restrict__ order, float4* __restrict__ tris,
+                                                     uint32_t slotBase)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= nnodes) return;
     const uint32_t first = nodes[i].first, count = nodes[i].count;
     if(count == 0) return;
-    float4* o = tris + (size_t)first * PRT_LEAF_SLOT_F4;
+    float4* o = tris + (size_t)(first + slotBase) * PRT_LEAF_SLOT_F4;
     for(uint32_t q = 0; q < count; ++q)
     {
         const uint32_t p = order[first + q];

@@ -41,6 +41,10 @@ struct SceneView
     const uint32_t*     scrTable;  // optional [32][npix]
     uint32_t            nmats, ntex, seed, ntri;
     BvhView             bvh;
+    // two-level scenes (kernels instantiated with TWO): instances in the caller's order
+    const float4*       shadeInst;  // 8 x float4 per instance (ShadeInst below)
+    const uint32_t*     instBase;   // flattened primitive id of every instance's first triangle (ninst + 1 entries)
+    uint32_t            ninst;
 };
 
 struct PathGen
@@ -305,8 +309,8 @@ struct ExtendIO
 #ifndef PRT_TRACE_ATTR
 #define PRT_TRACE_ATTR
 #endif
-template <bool INSTR>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_extend(SceneView sc, FrameView f, uint32_t generation,
+template <bool INSTR, bool TWO = false>
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, (INSTR || TWO) ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_extend(SceneView sc, FrameView f, uint32_t generation,
                                                             const uint32_t* __restrict__ countPtr,
                                                             uint32_t* workCtr, uint32_t primary, TraceTune tune)
 {
@@ -315,7 +319,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) 
     uint32_t            nskip = 0;
     TraceCount          tc    = {};
     ExtendIO            io(f.gen[generation & 1u], primary ? f.hitIds : nullptr);
-    trace_stream<false, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nskip, tc);
+    trace_stream<false, INSTR, ExtendIO, TWO>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nskip, tc);
     flush_counts<INSTR>(f, count, nskip, tc, 0);
 }
 
@@ -358,6 +362,47 @@ PRT_DEV TriU load_tri(const float4* __restrict__ stri, uint32_t prim)
     t.mat = __float_as_int(q6.x);
     return t;
 }
+// Two-level scenes: the flattened primitive `prim` belongs to the last instance whose base is <= prim; its triangle
+// record (object space) is taken to world space the way an instanced scene is flattened (host/Scene.cpp, oracle.cpp
+// shadingVertex): p = (M0*x + M1*y) + (M2*z + M3), n = normalize(N*n) with N = transpose(inverse(M)), a zero normal
+// stays zero, an identity instance is taken bit for bit.
+// ShadeInst record, 128 bytes: rows 0-2 object -> world (row i = (M[0][i], M[1][i], M[2][i], M[3][i])), rows 3-5 the
+// same rows of N (.w unused), row 6 = (first triangle of the bottom-level structure, flags: 1 = identity, -, -).
+PRT_DEV VertexU xform_corner(VertexU v, float4 m0, float4 m1, float4 m2, float4 n0, float4 n1, float4 n2)
+{
+    const f3 p = v.pos, n = v.normal;
+    v.pos = mk3((m0.x * p.x + m0.y * p.y) + (m0.z * p.z + m0.w), (m1.x * p.x + m1.y * p.y) + (m1.z * p.z + m1.w),
+                (m2.x * p.x + m2.y * p.y) + (m2.z * p.z + m2.w));
+    f3 nn = mk3((n0.x * n.x + n0.y * n.y) + n0.z * n.z, (n1.x * n.x + n1.y * n.y) + n1.z * n.z,
+                (n2.x * n.x + n2.y * n.y) + n2.z * n.z);
+    if(dot3(nn, nn) > 0.0f) nn = normalize3(nn);
+    v.normal = nn;
+    return v;
+}
+PRT_DEV TriU load_tri_inst(const SceneView& sc, uint32_t prim)
+{
+    uint32_t lo = 0, hi = sc.ninst;
+    while(hi - lo > 1u)
+    {
+        const uint32_t mid = (lo + hi) >> 1;
+        if(sc.instBase[mid] <= prim)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const float4*  rec   = sc.shadeInst + (size_t)lo * 8;
+    const float4   mt    = rec[6];
+    const uint32_t local = prim - sc.instBase[lo] + (uint32_t)__float_as_int(mt.x);
+    TriU           t     = load_tri(sc.stri, local);
+    if(!((uint32_t)__float_as_int(mt.y) & 1u))
+    {
+        const float4 m0 = rec[0], m1 = rec[1], m2 = rec[2], n0 = rec[3], n1 = rec[4], n2 = rec[5];
+        t.v0 = xform_corner(t.v0, m0, m1, m2, n0, n1, n2);
+        t.v1 = xform_corner(t.v1, m0, m1, m2, n0, n1, n2);
+        t.v2 = xform_corner(t.v2, m0, m1, m2, n0, n1, n2);
+    }
+    return t;
+}
 __global__ void __launch_bounds__(256) k_gather_shading(const prt_vertex* __restrict__ verts,
                                                         const uint32_t* __restrict__ idx, uint32_t ntri,
                                                         float4* __restrict__ stri)
@@ -377,7 +422,8 @@ __global__ void __launch_bounds__(256) k_gather_shading(const prt_vertex* __rest
 #ifndef PRT_SHADE_WAVES
 #define PRT_SHADE_WAVES 4  // 128 VGPRs, no scratch; 5 or 6 spill and are slower, 2-3 leave the compiler 132 VGPRs = 3 waves per SIMD
 #endif
-__global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,
+template <bool TWO = false>
+__global__ void __launch_bounds__(256, TWO ? 2 : PRT_SHADE_WAVES) k_shade(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,
                                                uint32_t bounce, const uint32_t* __restrict__ countIn,
                                                uint32_t* countNext, uint32_t* countShadow)
 {
@@ -500,7 +546,7 @@ __global__ void __launch_bounds__(256, PRT_SHADE_WAVES) k_shade(SceneView sc, Fr
                 const uint32_t scr1  = scramble_value(sc.scrTable, f.npixImg, sc.seed, ip, 2u * layer + 1u);
                 // sobolDim after the pixel offset is 4 + 4*bounce, 4 per vertex: tables 0..3 of sobT
 
-                const TriU     tri = load_tri(sc.stri, primitiveID);
+                const TriU     tri = TWO ? load_tri_inst(sc, primitiveID) : load_tri(sc.stri, primitiveID);
                 const VertexU &v0 = tri.v0, &v1 = tri.v1, &v2 = tri.v2;
                 const uint32_t      mi  = (tri.mat >= 0 && (uint32_t)tri.mat < sc.nmats) ? (uint32_t)tri.mat : 0u;
                 const prt_material& mat = sc.mats[mi];
@@ -748,8 +794,8 @@ struct ShadowIO
     }
 };
 
-template <bool INSTR>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow(SceneView sc, FrameView f,
+template <bool INSTR, bool TWO = false>
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, (INSTR || TWO) ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow(SceneView sc, FrameView f,
                                                             const uint32_t* __restrict__ countPtr, uint32_t* workCtr,
                                                             uint32_t bounce, TraceTune tune)
 {
@@ -758,7 +804,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) 
     uint32_t            nskip = 0;
     TraceCount          tc    = {};
     ShadowIO            io{f, f.contrib + (size_t)bounce * f.npix};
-    trace_stream<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nskip, tc);
+    trace_stream<true, INSTR, ShadowIO, TWO>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nskip, tc);
     flush_counts<INSTR>(f, count, nskip, tc, 1);
 }
 
@@ -766,8 +812,8 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) 
 // each other: one launch traces both. A wave first drains the extension queue (the next k_shade waits for it), then
 // the shadow queue, so the few long rays at the end of the first stream run beside the second stream instead of on
 // an empty GPU — one launch tail per bounce instead of two.
-template <bool INSTR>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow_extend(
+template <bool INSTR, bool TWO = false>
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, (INSTR || TWO) ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow_extend(
     SceneView sc, FrameView f, const uint32_t* __restrict__ shCountPtr, uint32_t* shWork, uint32_t bounce,
     const uint32_t* __restrict__ exCountPtr, uint32_t* exWork, TraceTune tune)
 {
@@ -777,7 +823,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) 
         uint32_t       nskip = 0;
         TraceCount     tc    = {};
         ExtendIO       io(f.gen[(bounce + 1u) & 1u], nullptr);
-        trace_stream<false, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, exWork, tune, io, nskip, tc);
+        trace_stream<false, INSTR, ExtendIO, TWO>(sc.bvh, &stackLds[threadIdx.x], count, exWork, tune, io, nskip, tc);
         flush_counts<INSTR>(f, count, nskip, tc, 0);
         if(blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(f.stats + 6, (unsigned long long)count);
     }
@@ -786,7 +832,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : PRT_TRACE_WAVES) 
         uint32_t       nskip = 0;
         TraceCount     tc    = {};
         ShadowIO       io{f, f.contrib + (size_t)bounce * f.npix};
-        trace_stream<true, INSTR>(sc.bvh, &stackLds[threadIdx.x], count, shWork, tune, io, nskip, tc);
+        trace_stream<true, INSTR, ShadowIO, TWO>(sc.bvh, &stackLds[threadIdx.x], count, shWork, tune, io, nskip, tc);
         flush_counts<INSTR>(f, count, nskip, tc, 1);
         if(blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(f.stats + 7, (unsigned long long)count);
     }
@@ -828,6 +874,7 @@ __global__ void __launch_bounds__(256) k_resolve(float4* __restrict__ accum, con
 // ---------------------------------------------------------------------------------------------
 // AO — AO.rgen:214-272, after k_ao_generate + k_extend
 // ---------------------------------------------------------------------------------------------
+template <bool TWO = false>
 __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, FrameView f, const prt_uniforms ubo_,
                                                               uint32_t flags, uint32_t* workCtr)
 {
@@ -864,7 +911,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
                 const uint32_t scr0 = scramble_value(sc.scrTable, f.npix, sc.seed, px, 0);
                 const uint32_t scr1 = scramble_value(sc.scrTable, f.npix, sc.seed, px, 1);
                 uint32_t sobolIndex = scramble_value(sc.scrTable, f.npix, sc.seed, px, 2);
-                const TriU     tri = load_tri(sc.stri, prim);
+                const TriU     tri = TWO ? load_tri_inst(sc, prim) : load_tri(sc.stri, prim);
                 const VertexU &v0 = tri.v0, &v1 = tri.v1, &v2 = tri.v2;
                 const f3      bary = mk3(1.0f - hq.y - hq.z, hq.y, hq.z);
                 const float4  rd4  = f.gen[0].rayD[px];
@@ -899,7 +946,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
                     const float hy = r * sn;
                     const float hz = __builtin_sqrtf(gmax(0.0f, 1.0f - hx * hx - hy * hy));
                     const f3    Rd = normalize3(mulM(onb, mk3(hx, hy, hz))) * mk3(aoLen);
-                    const Hit   h  = trace_ray<true>(sc.bvh, &stackLds[threadIdx.x], hitPoint, 0.00001f, Rd, 1.0f);
+                    const Hit   h  = trace_ray<true, false, TWO>(sc.bvh, &stackLds[threadIdx.x], hitPoint, 0.00001f, Rd, 1.0f);
                     if(h.prim == 0xffffffffu) noHit++;
                 }
                 nrays += (uint32_t)numAO;
@@ -963,8 +1010,8 @@ struct BatchIO
         hits[i] = make_float4(__int_as_float((int)h.prim), h.u, h.v, h.t);
     }
 };
-template <bool ANY>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) PRT_TRACE_ATTR k_trace_batch(BvhView bvh, const float4* __restrict__ rays,
+template <bool ANY, bool TWO = false>
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, TWO ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_trace_batch(BvhView bvh, const float4* __restrict__ rays,
                                                                  uint32_t n, float4* __restrict__ hits,
                                                                  uint32_t* workCtr, TraceTune tune,
                                                                  unsigned long long* stats)
@@ -973,7 +1020,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, PRT_TRACE_WAVES) PRT_TRACE_AT
     uint32_t            nskip = 0;
     TraceCount          tc    = {};
     BatchIO             io{rays, hits};
-    trace_stream<ANY, false>(bvh, &stackLds[threadIdx.x], n, workCtr, tune, io, nskip, tc);
+    trace_stream<ANY, false, BatchIO, TWO>(bvh, &stackLds[threadIdx.x], n, workCtr, tune, io, nskip, tc);
     if(tc.overrun && (threadIdx.x & 63) == 0) atomicAdd(stats + 28, 1ull);
 }
 

@@ -23,6 +23,11 @@
 //   The result of a trace is therefore independent of the tree and of the traversal order; the box
 //   test only has to be conservative: boxes grown by 64*2^-24*max(|origin|, |scene|), slab distances
 //   widened by 2^-21 (covers v_rcp_f32 + the fma rounding).
+// * Two-level scenes (instances of bottom-level structures, vkRT_TLAS.cpp:58-72): the TWO instantiations of
+//   trace_ray / trace_stream walk a top-level BVH4 over the instances' world boxes in the same node array; a lane
+//   that reaches an instance takes its ray to object space (same t), pushes an exit marker and walks the
+//   instance's structure; popping the marker restores the world-space ray. A hit is defined in object space
+//   (oracle.cpp: "instances"), so the top level, like every box test, only has to be conservative.
 #pragma once
 #include "prt_device.hpp"
 
@@ -50,7 +55,11 @@ namespace prt {
 static_assert(1 + 3 * (PRT_MAX_DEPTH / 2 + 1) <= PRT_LDS_STACK + PRT_SPILL_STACK && PRT_LDS_STACK >= 8, "stack covers the deepest tree");
 
 constexpr int32_t kSentinel  = 0x7fffffff;  // bottom-of-stack marker: the ray is finished
+constexpr int32_t kInstExit  = 0x7ffffffe;  // two-level scenes: the entries above this one belong to an instance
 constexpr int32_t kEmptyLeaf = -1;          // ~0: leaf reference with count 0
+// two-level scenes: the top-level tree is limited to 32 binary levels (<= 51 stack entries), + 1 exit marker
+#define PRT_TLAS_MAX_DEPTH 32
+#define PRT_SPILL_STACK_TWO (PRT_SPILL_STACK + 3 * (PRT_TLAS_MAX_DEPTH / 2 + 1) + 1)
 
 struct BvhView
 {
@@ -59,7 +68,15 @@ struct BvhView
     int32_t       root;   // node index (0), or a leaf reference when the scene has <= 4 triangles
     float         sceneAbs;
     float         qmin[3], qscale[3];  // box coordinate = qmin + q * qscale, q in [0, 65535]
+    // Two-level scenes (kernels instantiated with TWO): root / sceneAbs / the grid above are the top-level
+    // structure's, whose leaves are single instances; all structures share `nodes` and `tris`.
+    const float4* inst;      // 8 x float4 per instance, in top-level leaf order (InstanceRec below)
+    float         padScale;  // widening of the top-level box test: covers the rounding of the object-space transforms
 };
+// Instance record, 128 bytes: rows 0-2 world -> object (row i = (W[0][i], W[1][i], W[2][i], W[3][i]) of the
+// column-major inverse transform), row 3 = qmin.xyz | sceneAbs of the bottom-level structure, row 4 = qscale.xyz | root
+// reference (int bits), row 5 = (flattened primitive id of its first triangle, flags: 1 = identity transform, -, -).
+#define PRT_INST_F4 8
 
 struct Hit
 {
@@ -99,6 +116,7 @@ struct RayCtx
 
 PRT_DEV float sel3(float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); }
 
+template <bool TOP = false>
 PRT_DEV void ray_prepare(const BvhView& bvh, f3 o, float tmin, f3 d, float tmax, RayCtx& r)
 {
     r.ox = o.x; r.oy = o.y; r.oz = o.z;
@@ -125,7 +143,8 @@ PRT_DEV void ray_prepare(const BvhView& bvh, f3 o, float tmin, f3 d, float tmax,
     amax       = gmax(amax, gabs(o.x));
     amax       = gmax(amax, gabs(o.y));
     amax       = gmax(amax, gabs(o.z));
-    const float pad = 3.814697265625e-06f * amax;
+    float pad = 3.814697265625e-06f * amax;
+    if(TOP) pad = pad * bvh.padScale;  // top level of a two-level scene
     // plane distance t = (qmin + q*qscale - (o +- pad)) * rd, widened by 2^-21, as one fma on float(q)
 #define PRT_SLAB_SETUP(c, k, rn, cn, rf, cf, ng)                     \
     {                                                                \
@@ -318,8 +337,10 @@ PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_
 }
 
 // All triangles of one leaf. Returns true when an ANY ray found an occluder.
+// sceneAbs / primBase: of the structure the lane is in (single-level: bvh.sceneAbs, 0)
 template <bool ANY, bool INSTR>
-PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit& best, TraceCount& tc)
+PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit& best, TraceCount& tc, float sceneAbs,
+                       uint32_t primBase)
 {
     const uint32_t ref   = ~(uint32_t)leafRef;
     const uint32_t first = ref >> 3, count = ref & 7u;
@@ -344,9 +365,9 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
 #endif
         float tt, uu, vv;
         if(INSTR) tc.tris++;
-        if(tri_test(r, bvh.sceneAbs, a, b, c, tt, uu, vv))
+        if(tri_test(r, sceneAbs, a, b, c, tt, uu, vv))
         {
-            const uint32_t p = (uint32_t)__float_as_int(a.w);
+            const uint32_t p = primBase + (uint32_t)__float_as_int(a.w);
             if(ANY)
             {
                 best.prim = p;
@@ -379,22 +400,78 @@ PRT_DEV Hit hit_none(float tmax)
     return h;
 }
 
+// ---- two-level scenes: entering and leaving an instance ------------------------------------------------
+// The lane's ray in the object space of the instance behind top-level leaf `ref`, its slab constants on that
+// structure's grid; returns the structure's root reference (an empty leaf for an empty slot).
+PRT_DEV int32_t instance_enter(const BvhView& bvh, int32_t ref, f3 o, float tmin, f3 d, float tmax, RayCtx& r,
+                               float& curAbs, uint32_t& primBase)
+{
+    const uint32_t lref = ~(uint32_t)ref;
+    if((lref & 7u) == 0u) return kEmptyLeaf;
+    const float4* rec = bvh.inst + (size_t)(lref >> 3) * PRT_INST_F4;
+    const float4  w0 = rec[0], w1 = rec[1], w2 = rec[2], g0 = rec[3], g1 = rec[4], mt = rec[5];
+    if(!((uint32_t)__float_as_int(mt.y) & 1u))
+    {
+        // o' = (W0*o.x + W1*o.y) + (W2*o.z + W3), d' = (W0*d.x + W1*d.y) + W2*d.z: the oracle's rayToObject
+        const f3 oo = mk3((w0.x * o.x + w0.y * o.y) + (w0.z * o.z + w0.w), (w1.x * o.x + w1.y * o.y) + (w1.z * o.z + w1.w),
+                          (w2.x * o.x + w2.y * o.y) + (w2.z * o.z + w2.w));
+        const f3 od = mk3((w0.x * d.x + w0.y * d.y) + w0.z * d.z, (w1.x * d.x + w1.y * d.y) + w1.z * d.z,
+                          (w2.x * d.x + w2.y * d.y) + w2.z * d.z);
+        o = oo;
+        d = od;
+    }
+    BvhView ob   = bvh;
+    ob.qmin[0]   = g0.x; ob.qmin[1] = g0.y; ob.qmin[2] = g0.z;
+    ob.qscale[0] = g1.x; ob.qscale[1] = g1.y; ob.qscale[2] = g1.z;
+    ob.sceneAbs  = g0.w;
+    ray_prepare(ob, o, tmin, d, tmax, r);
+    curAbs   = g0.w;
+    primBase = (uint32_t)__float_as_int(mt.x);
+    return __float_as_int(g1.w);
+}
+
 // ---- one ray per lane, all lanes start together (AO rays inside k_ao_shade) ---------------------------
 // ANY = true: terminate-on-first-hit / skip-closest-hit-shader occlusion query (prim != ~0u on hit).
 // INSTR = true additionally counts node visits and triangle tests (profiling level 2).
-template <bool ANY, bool INSTR = false>
+template <bool ANY, bool INSTR = false, bool TWO = false>
 PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, f3 o, float tmin, f3 d, float tmax, TraceCount* tcp = nullptr)
 {
     RayCtx r;
-    ray_prepare(bvh, o, tmin, d, tmax, r);
+    ray_prepare<TWO>(bvh, o, tmin, d, tmax, r);
     Hit        best = hit_none(tmax);
     TraceCount tc   = {};
-    int32_t    spill[PRT_SPILL_STACK];
+    int32_t    spill[TWO ? PRT_SPILL_STACK_TWO : PRT_SPILL_STACK];
     PRT_STACK_AT(lds, 0) = (uint32_t)kSentinel;
-    int     sp  = 1;
-    int32_t cur = bvh.root;
+    int      sp       = 1;
+    int32_t  cur      = bvh.root;
+    float    curAbs   = bvh.sceneAbs;
+    uint32_t primBase = 0;
+    bool     inInst   = false;
     while(cur != kSentinel)
     {
+        if(TWO)
+        {
+            if(cur == kInstExit)
+            {
+                ray_prepare<true>(bvh, o, tmin, d, tmax, r);
+                inInst = false;
+                cur    = stack_pop(sp, lds, spill);
+                continue;
+            }
+            if(cur < 0 && !inInst)
+            {
+                const int32_t root = instance_enter(bvh, cur, o, tmin, d, tmax, r, curAbs, primBase);
+                if(root == kEmptyLeaf)
+                    cur = stack_pop(sp, lds, spill);
+                else
+                {
+                    stack_push_slow(sp, lds, spill, kInstExit);
+                    inInst = true;
+                    cur    = root;
+                }
+                continue;
+            }
+        }
         if(cur >= 0)
         {
             if(INSTR) tc.nodes++;
@@ -402,7 +479,7 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, f3 o, float tmin, f3 d,
         }
         else
         {
-            if(leaf_test<ANY, INSTR>(bvh, r, cur, best, tc)) break;
+            if(leaf_test<ANY, INSTR>(bvh, r, cur, best, tc, TWO ? curAbs : bvh.sceneAbs, TWO ? primBase : 0u)) break;
             cur = stack_pop(sp, lds, spill);
         }
     }
@@ -417,7 +494,10 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, f3 o, float tmin, f3 d,
 // ---- persistent wave: a stream of `count` rays ----------------------------------------------------------
 // IO::load(i, o, tmin, d, tmax, tag) -> bool (false: a placeholder that does not count in the statistics);
 // IO::store(tag, hit) is called once per ray when it has finished.
-template <bool ANY, bool INSTR, class IO>
+// TWO: two-level scene. A lane at the top level that reaches a leaf (= an instance) enters it at the next node step;
+// a lane that pops the exit marker leaves the instance once its postponed leaf (which belongs to the instance) has
+// been tested. The world-space ray is read again from the queue (io.load is a pure function of the slot).
+template <bool ANY, bool INSTR, class IO, bool TWO = false>
 PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uint32_t* workCtr, const TraceTune tune,
                           IO& io, uint32_t& nskipped, TraceCount& tc)
 {
@@ -428,10 +508,15 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
     bool                     active    = false;
     int32_t                  cur = kSentinel, leaf = kEmptyLeaf;
     int                      sp = 1;
-    int32_t                  spill[PRT_SPILL_STACK];
+    int32_t                  spill[TWO ? PRT_SPILL_STACK_TWO : PRT_SPILL_STACK];
     RayCtx                   r;
     Hit                      best = hit_none(0.0f);
     uint32_t                 tag  = 0;
+    // two-level scenes: the structure the lane is in
+    float                    curAbs   = bvh.sceneAbs;
+    uint32_t                 primBase = 0;
+    bool                     inInst   = false;
+    constexpr int32_t        kStepEnd = TWO ? kInstExit : kSentinel;  // references below this are inner nodes
     r.tmin = r.tmax = 0.0f;
     PRT_STACK_AT(lds, 0) = (uint32_t)kSentinel;  // bottom of the lane's stack; sp >= 1 always
 
@@ -478,12 +563,13 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
                 f3    o, d;
                 float tmin, tmax;
                 if(!io.load(chunkPos + rank, o, tmin, d, tmax, tag)) nskipped++;
-                ray_prepare(bvh, o, tmin, d, tmax, r);
+                ray_prepare<TWO>(bvh, o, tmin, d, tmax, r);
                 best   = hit_none(tmax);
                 cur    = bvh.root;
                 leaf   = kEmptyLeaf;
                 sp     = 1;
                 active = true;
+                if(TWO) inInst = false;
             }
             chunkPos += take;
         }
@@ -503,32 +589,64 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
         //      it and keeps descending; lanes at a second leaf (or finished) wait
         for(;;)
         {
+            if(TWO && active)
+            {
+                if(cur == kInstExit && leaf == kEmptyLeaf)
+                {
+                    f3       o, d;
+                    float    tmin, tmax;
+                    uint32_t tg;
+                    io.load(tag, o, tmin, d, tmax, tg);
+                    ray_prepare<true>(bvh, o, tmin, d, tmax, r);
+                    inInst = false;
+                    cur    = stack_pop(sp, lds, spill);
+                }
+                if(cur < 0 && !inInst)
+                {
+                    f3       o, d;
+                    float    tmin, tmax;
+                    uint32_t tg;
+                    io.load(tag, o, tmin, d, tmax, tg);
+                    const int32_t root = instance_enter(bvh, cur, o, tmin, d, tmax, r, curAbs, primBase);
+                    if(root == kEmptyLeaf)
+                        cur = stack_pop(sp, lds, spill);
+                    else
+                    {
+                        stack_push_slow(sp, lds, spill, kInstExit);
+                        inInst = true;
+                        cur    = root;
+                    }
+                }
+            }
             if(INSTR)
             {
-                const uint32_t n = (uint32_t)__popcll(__ballot(active && (uint32_t)cur < (uint32_t)kSentinel));
+                const uint32_t n = (uint32_t)__popcll(__ballot(active && (uint32_t)cur < (uint32_t)kStepEnd));
                 if(lane == 0 && n)
                 {
                     tc.wNode++;
                     tc.lNode += n;
                 }
             }
-            if(active && (uint32_t)cur < (uint32_t)kSentinel)
+            if(active && (uint32_t)cur < (uint32_t)kStepEnd)
             {
                 if(INSTR) tc.nodes++;
                 node4_step<ANY>(bvh, r, best.t, cur, sp, lds, spill);
-                if(cur < 0 && leaf == kEmptyLeaf)
+                if(cur < 0 && leaf == kEmptyLeaf && (!TWO || inInst))
                 {
                     leaf = cur;
                     cur  = stack_pop(sp, lds, spill);
                 }
             }
-            const uint32_t nProd = (uint32_t)__popcll(__ballot(active && (uint32_t)cur < (uint32_t)kSentinel));
+            // lanes that can go on in this phase: at an inner node, or (two-level) about to enter / leave an instance
+            const bool prod = active && ((uint32_t)cur < (uint32_t)kStepEnd ||
+                                         (TWO && ((cur == kInstExit && leaf == kEmptyLeaf) || (cur < 0 && !inInst))));
+            const uint32_t nProd = (uint32_t)__popcll(__ballot(prod));
             if(nProd == 0 || nActive - nProd > tune.stallMax) break;
         }
 
         PRT_LAP(cNode)
         // ---- triangle phase
-        if(active && leaf == kEmptyLeaf && cur < 0)
+        if(active && leaf == kEmptyLeaf && cur < 0 && (!TWO || inInst))
         {
             leaf = cur;
             cur  = stack_pop(sp, lds, spill);
@@ -557,7 +675,7 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
             }
             if(has)
             {
-                const bool occluded = leaf_test<ANY, INSTR>(bvh, r, leaf, best, tc);
+                const bool occluded = leaf_test<ANY, INSTR>(bvh, r, leaf, best, tc, TWO ? curAbs : bvh.sceneAbs, TWO ? primBase : 0u);
                 leaf                = kEmptyLeaf;
                 if(ANY && occluded)
                 {

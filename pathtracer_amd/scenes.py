@@ -35,7 +35,11 @@ MATERIAL_DTYPE = np.dtype(
         ("pad", "<f4"),
     ]
 )
-assert VERTEX_DTYPE.itemsize == 48 and MATERIAL_DTYPE.itemsize == 96
+# include/prt_types.h: prt_blas_range / prt_instance (transform: column-major mat4, object -> world)
+BLAS_DTYPE = np.dtype([("first_triangle", "<u4"), ("n_triangles", "<u4")])
+INSTANCE_DTYPE = np.dtype([("transform", "<f4", 16), ("blas", "<u4"), ("instance_id", "<u4"), ("hit_group", "<u4"),
+                           ("pad", "<u4")])
+assert VERTEX_DTYPE.itemsize == 48 and MATERIAL_DTYPE.itemsize == 96 and INSTANCE_DTYPE.itemsize == 80
 
 
 def make_material(diffuse=(0.8, 0.8, 0.8), specular=(0.0, 0.0, 0.0), roughness=None, dissolve=1.0,
@@ -482,3 +486,86 @@ def san_miguel_scale(seed=5, million_tris=10.0):
     sc["camera"] = _lookat_pose((-S / 2 + 1.5, 1.8, -S / 2 + 1.5), (2.0, 3.0, 2.0))
     sc["light"] = {"pos": (0.0, Ht - 0.4, 0.0), "dir": (0.0, -1.0, 0.0)}
     return sc
+
+
+# ----------------------------------------------------------------------------------------------
+# two-level scenes (vkRT_TLAS.cpp:58-72: instances of bottom-level structures with transforms)
+# ----------------------------------------------------------------------------------------------
+def affine(scale=(1.0, 1.0, 1.0), axis=(0.0, 1.0, 0.0), angle=0.0, translate=(0.0, 0.0, 0.0), shear_xy=0.0):
+    """Column-major mat4 (16 floats, glm layout) of T * R(axis, angle) * Shear * S."""
+    ax = np.asarray(axis, np.float64)
+    ax = ax / np.linalg.norm(ax)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+    Sh = np.eye(3)
+    Sh[0, 1] = shear_xy
+    A = R @ Sh @ np.diag(np.broadcast_to(np.asarray(scale, np.float64), 3))
+    M = np.eye(4)
+    M[:3, :3] = A
+    M[:3, 3] = translate
+    return np.ascontiguousarray(M.T.reshape(16).astype(np.float32))  # column-major
+
+
+def instanced_scene(seed=11, n_instances=24, detail=1.0, wild=False):
+    """A closed room (structure 0, one identity instance) furnished with instances of three small models: a smooth
+    sphere-on-a-stem "tree", a box and a bumpy quad-grid "shrub". Transforms: rotations about random axes, uniform and
+    (wild=True) non-uniform scales, mirrors and shears. Returns a scene dict with two more keys, "blas" (BLAS_DTYPE)
+    and "instances" (INSTANCE_DTYPE); vertices are in object space."""
+    rng = np.random.default_rng(seed)
+    mats = [
+        make_material((0.7, 0.7, 0.68), roughness=0.9),  # 0 walls
+        make_material((0.25, 0.5, 0.2), (0.05, 0.05, 0.05), roughness=0.5),  # 1 foliage
+        make_material((0.45, 0.3, 0.2), roughness=0.8),  # 2 wood
+        make_material((0.6, 0.6, 0.65), (0.6, 0.6, 0.6), roughness=0.15),  # 3 metal
+        make_material((0.9, 0.9, 0.9), (0.04, 0.04, 0.04), roughness=0.05, dissolve=0.0),  # 4 glass
+    ]
+    S, H = 10.0, 4.0
+    parts = []
+    mb = MeshBuilder()  # structure 0: the room
+    g = max(2, int(8 * detail))
+    mb.quad_grid((-S / 2, 0, -S / 2), (0, 0, S), (S, 0, 0), g, g, 0)
+    mb.quad_grid((-S / 2, H, -S / 2), (S, 0, 0), (0, 0, S), g, g, 0)
+    for (o, eu, ev) in (((-S / 2, 0, -S / 2), (S, 0, 0), (0, H, 0)), ((-S / 2, 0, S / 2), (0, H, 0), (S, 0, 0)),
+                        ((-S / 2, 0, -S / 2), (0, H, 0), (0, 0, S)), ((S / 2, 0, -S / 2), (0, 0, S), (0, H, 0))):
+        mb.quad_grid(o, eu, ev, g, g, 0)
+    parts.append(mb)
+    mb = MeshBuilder()  # structure 1: tree
+    mb.cylinder((0.0, 0.0, 0.0), 0.06, 0.7, max(6, int(10 * detail)), 2, rings=2)
+    mb.sphere((0.0, 0.95, 0.0), 0.35, max(8, int(16 * detail)), max(6, int(10 * detail)), 1)
+    parts.append(mb)
+    mb = MeshBuilder()  # structure 2: box
+    mb.box((-0.3, 0.0, -0.3), (0.3, 0.6, 0.3), 3, n=max(1, int(2 * detail)))
+    parts.append(mb)
+    mb = MeshBuilder()  # structure 3: shrub
+    bump = lambda S_, T_: np.stack([np.zeros_like(S_), 0.15 * np.sin(9 * S_) * np.cos(7 * T_), np.zeros_like(S_)], -1)
+    mb.quad_grid((-0.4, 0.3, -0.4), (0.8, 0, 0), (0, 0, 0.8), max(4, int(10 * detail)), max(4, int(10 * detail)), 4,
+                 displace=bump)
+    parts.append(mb)
+    scs = [m.finish(mats) for m in parts]
+    verts = np.concatenate([x["vertices"] for x in scs])
+    ntris = [len(x["indices"]) // 3 for x in scs]
+    blas = np.zeros(len(scs), BLAS_DTYPE)
+    blas["n_triangles"] = ntris
+    blas["first_triangle"] = np.concatenate([[0], np.cumsum(ntris)[:-1]])
+    inst = np.zeros(1 + n_instances, INSTANCE_DTYPE)
+    inst[0]["transform"] = affine()
+    for i in range(1, 1 + n_instances):
+        k = int(rng.integers(1, len(scs)))
+        sc_u = float(rng.uniform(0.5, 1.6))
+        scale = (sc_u, sc_u, sc_u)
+        shear = 0.0
+        axis = (0.0, 1.0, 0.0)
+        if wild:
+            scale = tuple(float(v) for v in sc_u * rng.uniform(0.4, 1.5, 3) * rng.choice([1.0, -1.0], 3, p=[0.8, 0.2]))
+            shear = float(rng.uniform(-0.5, 0.5))
+            axis = tuple(rng.normal(0, 1, 3))
+        pos = (float(rng.uniform(-S / 2 + 1, S / 2 - 1)), float(rng.uniform(0.0, 1.5 if wild else 0.0)),
+               float(rng.uniform(-S / 2 + 1, S / 2 - 1)))
+        inst[i]["transform"] = affine(scale, axis, float(rng.uniform(0, 2 * np.pi)), pos, shear)
+        inst[i]["blas"] = k
+        inst[i]["instance_id"] = 100 + i
+    out = {"vertices": verts, "indices": np.arange(len(verts), dtype=np.uint32), "materials": scs[0]["materials"],
+           "textures": [], "blas": blas, "instances": inst, "name": "instanced"}
+    out["camera"] = _lookat_pose((-S / 2 + 0.8, 1.7, -S / 2 + 0.8), (0.5, 0.8, 0.5))
+    out["light"] = {"pos": (0.0, H - 0.3, 0.0), "dir": (0.0, -1.0, 0.0)}
+    return out

@@ -1,0 +1,226 @@
+"""GPU parity tests of two-level scenes (prt_set_instances: instances of bottom-level structures with transforms,
+/root/reference/external/NVIDIA_RTX/vkRT_TLAS.cpp:58-72) against the CPU oracle's definition (object-space
+intersection, oracle.cpp "instances"; PARITY UNPINNED like the single-level trace). Bar: hits, primary ids, ray counts
+and the fp32 image bit-exact."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import capi, scenes, uniforms
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+import instancing  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(po, sc, W, H, seed=3, flags=0):
+    o = po.Oracle(sc, seed=seed)
+    o.set_instances(sc["blas"], sc["instances"])
+    o.build_bvh()
+    ctx = capi.Context(W, H)
+    ctx.set_scene(sc)
+    ctx.set_instances(sc["blas"], sc["instances"])
+    ctx.set_seed(seed)
+    ctx.build_accel()
+    ctx.set_flags(flags)
+    return o, ctx
+
+
+def _rays(n, seed, tmax=100.0, nan_every=0):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, capi.RAY_DTYPE)
+    rays["o"] = rng.uniform(-4.5, 4.5, (n, 3))
+    rays["o"][:, 1] = rng.uniform(0.1, 3.9, n)
+    rays["d"] = rng.normal(0, 1, (n, 3)) * rng.uniform(0.2, 3.0, (n, 1))
+    # some axis-parallel and some far-away rays
+    rays["d"][::17, 0] = 0.0
+    rays["d"][::29, 1:] = 0.0
+    rays["o"][::23] *= 40.0
+    rays["tmin"] = 1e-6
+    rays["tmax"] = tmax
+    if nan_every:
+        rays["d"][::nan_every, 2] = np.nan
+    return rays
+
+
+@pytest.mark.parametrize("wild,n_inst,seed", [(False, 24, 11), (True, 24, 12), (True, 300, 13), (True, 1, 14)])
+def test_instanced_trace_equals_oracle_brute_force(po, wild, n_inst, seed):
+    sc = scenes.instanced_scene(seed=seed, n_instances=n_inst, wild=wild)
+    o, ctx = _pair(po, sc, 16, 16)
+    rays = _rays(60000, seed, nan_every=997)
+    g = ctx.trace(rays)
+    ref = o.trace_closest(rays, brute=True)
+    assert g.tobytes() == ref.tobytes(), f"{int((g['prim'] != ref['prim']).sum())} closest hits differ"
+    short = _rays(60000, seed + 100, tmax=1.0)
+    ga = ctx.trace(short, any_hit=True)["prim"] != 0xFFFFFFFF
+    ra = o.trace_any(short, brute=True).astype(bool)
+    assert (ga == ra).all() and 0.02 < ra.mean() < 0.98
+    assert ctx.stats().trace_overruns == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode,bounces,flags", [(0, 3, 0), (0, 5, capi.FLAG_RUSSIAN_ROULETTE), (1, 0, 0),
+                                                (0, 2, capi.FLAG_LITERAL)])
+def test_instanced_image_bit_exact(po, mode, bounces, flags):
+    sc = scenes.instanced_scene(seed=15, n_instances=20, wild=True)
+    W, H = 96, 64
+    o, ctx = _pair(po, sc, W, H, flags=flags)
+    acc = np.zeros((H, W, 4), np.float32)
+    for it in (1, 2, 3):
+        u = uniforms.make_uniforms(sc, W, H, iteration=it, bounces=bounces, ao_rays=8)
+        acc, ids, rays = o.render(u, W, H, mode, accum=acc, flags=flags, want_ids=True)
+        ctx.set_uniforms(u)
+        ctx.reset_stats()
+        ctx.render_iteration(mode)
+        g = ctx.read_accum()
+        assert (ctx.read_hit_ids() == ids).all(), f"iteration {it}: primary hit ids differ"
+        assert ctx.stats().rays == rays
+        nd = int((g.view(np.uint32) != acc.view(np.uint32)).any(axis=-1).sum())
+        assert nd == 0, f"iteration {it}: {nd} pixels differ"
+    ctx.close()
+
+
+def test_instanced_batched_render_bit_exact(po):
+    """prt_render (several iterations per pass, pipelined) on a two-level scene = the oracle iteration by iteration."""
+    sc = scenes.instanced_scene(seed=16, n_instances=30, wild=False)
+    W, H = 80, 60
+    o, ctx = _pair(po, sc, W, H)
+    u = uniforms.make_uniforms(sc, W, H, iteration=1, bounces=4)
+    ctx.set_uniforms(u)
+    ctx.set_iteration_batch(4)
+    ctx.render(capi.MODE_PATH, 1, 7)
+    g = ctx.read_accum()
+    acc = np.zeros((H, W, 4), np.float32)
+    for it in range(1, 8):
+        acc, _, _ = o.render(uniforms.make_uniforms(sc, W, H, iteration=it, bounces=4), W, H, 0, accum=acc)
+    assert g.tobytes() == acc.tobytes()
+    ctx.close()
+
+
+def test_identity_instance_equals_single_level_context(po):
+    """What the reference wires — one identity instance of model 0 (vkRTX_setup.cpp:138-186) — gives the bits of the
+    single-level path."""
+    sc = scenes.conference_room(detail=0.3)
+    W, H = 64, 48
+    u = uniforms.make_uniforms(sc, W, H, iteration=1, bounces=3)
+    imgs, ids = [], []
+    for two in (False, True):
+        ctx = capi.Context(W, H)
+        ctx.set_scene(sc)
+        if two:
+            inst = np.zeros(1, capi.INSTANCE_DTYPE)
+            inst["transform"][0] = scenes.affine()
+            ctx.set_instances(np.array([(0, len(sc["indices"]) // 3)], capi.BLAS_DTYPE), inst)
+        ctx.set_seed(3)
+        ctx.build_accel()
+        ctx.set_uniforms(u)
+        ctx.render(capi.MODE_PATH, 1, 3)
+        imgs.append(ctx.read_accum())
+        ids.append(ctx.read_hit_ids())
+        ctx.close()
+    assert imgs[0].tobytes() == imgs[1].tobytes() and (ids[0] == ids[1]).all()
+
+
+def test_instanced_close_to_flattened(po):
+    """Against the host-flattened scene (pathtracer_amd/host/Scene.cpp semantics, world-space triangles): the same
+    primitives up to grazing cases and the same image up to the rounding of the object-space transforms."""
+    sc = scenes.instanced_scene(seed=17, n_instances=16, wild=True)
+    W, H = 96, 64
+    u = uniforms.make_uniforms(sc, W, H, iteration=1, bounces=3)
+    ctx = capi.Context(W, H)
+    ctx.set_scene(sc)
+    ctx.set_instances(sc["blas"], sc["instances"])
+    ctx.build_accel()
+    ctx.set_uniforms(u)
+    ctx.render(capi.MODE_PATH, 1, 4)
+    a, ia = ctx.read_accum(), ctx.read_hit_ids()
+    nodes_two = ctx.stats().bvh_inner_nodes
+    ctx.close()
+    ctx = capi.Context(W, H)
+    ctx.set_scene(instancing.flatten(sc))
+    ctx.build_accel()
+    ctx.set_uniforms(u)
+    ctx.render(capi.MODE_PATH, 1, 4)
+    b, ib = ctx.read_accum(), ctx.read_hit_ids()
+    nodes_flat = ctx.stats().bvh_inner_nodes
+    ctx.close()
+    assert (ia == ib).mean() > 0.999
+    assert float(((a - b) ** 2).sum() / (b ** 2).sum()) < 1e-6
+    assert nodes_two < nodes_flat  # the structures are shared, not copied per instance
+
+
+def test_blas_trees_are_the_oracle_trees(po):
+    sc = scenes.instanced_scene(seed=18, n_instances=5)
+    o, ctx = _pair(po, sc, 16, 16)
+    for k in range(len(sc["blas"])):
+        gn, go = ctx.read_blas_bvh(k)
+        on, oo = o.blas_bvh(k)
+        assert gn.tobytes() == on.tobytes() and (go == oo).all()
+    ctx.close()
+
+
+def test_instance_transform_update_equals_fresh_build(po):
+    sc = scenes.instanced_scene(seed=19, n_instances=40, wild=True)
+    sc2 = scenes.instanced_scene(seed=20, n_instances=40, wild=True)
+    sc2["instances"]["blas"] = sc["instances"]["blas"]  # same structures, new placements
+    o, ctx = _pair(po, sc, 16, 16)
+    rays = _rays(30000, 5)
+    ctx.update_instance_transforms(sc2["instances"]["transform"])
+    g = ctx.trace(rays)
+    o2 = po.Oracle(sc, seed=3)
+    o2.set_instances(sc["blas"], sc2["instances"])
+    assert g.tobytes() == o2.trace_closest(rays, brute=True).tobytes()
+    ctx.close()
+
+
+def test_refit_of_an_instanced_scene(po):
+    sc = scenes.instanced_scene(seed=21, n_instances=10)
+    o, ctx = _pair(po, sc, 16, 16)
+    v = sc["vertices"].copy()
+    rng = np.random.default_rng(3)
+    v["p"] += rng.normal(0, 0.02, v["p"].shape).astype(np.float32)
+    ctx.update_vertices(v)
+    with pytest.raises(capi.PrtError):
+        ctx.trace(_rays(10, 1))
+    ctx.refit_accel()
+    sc_moved = dict(sc, vertices=v)
+    o2 = po.Oracle(sc_moved, seed=3)
+    o2.set_instances(sc["blas"], sc["instances"])
+    rays = _rays(30000, 6)
+    assert ctx.trace(rays).tobytes() == o2.trace_closest(rays, brute=True).tobytes()
+    ctx.close()
+
+
+def test_instance_errors():
+    sc = scenes.instanced_scene(seed=22, n_instances=3)
+    ctx = capi.Context(16, 16)
+    inst = sc["instances"].copy()
+    with pytest.raises(capi.PrtError):  # no scene yet
+        ctx.set_instances(sc["blas"], inst)
+    ctx.set_scene(sc)
+    bad = inst.copy()
+    bad["transform"][1][3] = 0.5  # projective fourth row
+    with pytest.raises(capi.PrtError):
+        ctx.set_instances(sc["blas"], bad)
+    bad = inst.copy()
+    bad["blas"][2] = 99
+    with pytest.raises(capi.PrtError):
+        ctx.set_instances(sc["blas"], bad)
+    blas = sc["blas"].copy()
+    blas["n_triangles"][0] = 10 ** 9
+    with pytest.raises(capi.PrtError):
+        ctx.set_instances(blas, inst)
+    sing = inst.copy()
+    sing["transform"][1] = scenes.affine(scale=(1.0, 0.0, 1.0))
+    ctx.set_instances(sc["blas"], sing)
+    with pytest.raises(capi.PrtError):  # singular transform: refused at build time
+        ctx.build_accel()
+    ctx.set_instances(sc["blas"], inst)
+    ctx.build_accel()
+    ctx.set_instances(sc["blas"][:0], inst[:0])  # back to the single-level scene
+    ctx.build_accel()
+    assert ctx.read_bvh()[0].shape[0] > 0
+    ctx.close()

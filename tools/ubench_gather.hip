@@ -7,6 +7,7 @@
 //   C  every lane reads 16 bytes of its own random record, one load                  (cost of one divergent instruction)
 //   D  like A with 80-byte records and five loads                                      (the 8-wide node visit)
 //   E  like B for 128-byte records: eight lanes per record, eight instructions
+//   F  like A with aligned 128-byte records and eight loads                           (an 8-wide node with 16-bit planes)
 // Records come from a table of `tableMB` megabytes; indices are an LCG per lane, and each round's index depends on
 // the data of the round before (a dependent chain per lane, as in a traversal).
 //
@@ -66,6 +67,12 @@ __global__ void __launch_bounds__(256, 6) k_gather(const uint4* __restrict__ tab
             const uint4* p = table + (size_t)idx * 5;
             const uint4  a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
             acc += a.x ^ b.y ^ c.z ^ d.w ^ e.x;
+        }
+        else if(MODE == 5)
+        {
+            const uint4* p = table + (size_t)idx * 8;
+            const uint4  a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g = p[6], h = p[7];
+            acc += a.x ^ b.y ^ c.z ^ d.w ^ e.x ^ f.y ^ g.z ^ h.w;
         }
         else
         {
@@ -128,6 +135,7 @@ int main(int argc, char** argv)
         case 'A': run<0>("A  lane: 4 x 16 B of its own 64-B record", table, tableBytes, 64, 4, out, blocks); break;
         case 'C': run<2>("C  lane: 16 B of its own record, 1 load", table, tableBytes, 64, 1, out, blocks); break;
         case 'D': run<3>("D  lane: 5 x 16 B of its own 80-B record", table, tableBytes, 80, 5, out, blocks); break;
+        case 'F': run<5>("F  lane: 8 x 16 B of its own 128-B record", table, tableBytes, 128, 8, out, blocks); break;
         default: run<4>("E  oct: 8 records of 128 B, 16 B per lane", table, tableBytes, 128, 8, out, blocks); break;
         }
         return 0;
@@ -137,5 +145,6 @@ int main(int argc, char** argv)
     run<2>("C  lane: 16 B of its own record, 1 load", table, tableBytes, 64, 1, out, blocks);
     run<3>("D  lane: 5 x 16 B of its own 80-B record", table, tableBytes, 80, 5, out, blocks);
     run<4>("E  oct: 8 records of 128 B, 16 B per lane", table, tableBytes, 128, 8, out, blocks);
+    run<5>("F  lane: 8 x 16 B of its own 128-B record", table, tableBytes, 128, 8, out, blocks);
     return 0;
 }
