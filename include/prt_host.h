@@ -79,6 +79,20 @@ typedef struct prth_instance
  * n_instances + 1 entries: gl_PrimitiveID base of every instance, then the total. */
 int prth_flatten_instances(const prth_model* const* models, size_t n_models, const prth_instance* instances,
                            size_t n_instances, prth_model** out, uint32_t* first_triangle, char* err, size_t err_len);
+/* The same models side by side in one object-space pool + one bottom-level range per model + the instance list: what
+ * prt_set_scene + prt_set_instances take (Scene.h poolInstances). ranges: n_models entries, instances_out: n_instances. */
+int prth_pool_instances(const prth_model* const* models, size_t n_models, const prth_instance* instances,
+                        size_t n_instances, prth_model** out, prt_blas_range* ranges, prt_instance* instances_out, char* err,
+                        size_t err_len);
+/* Renderer::initRaytracing(models, instances, flatten) -> n iterations -> image (and, optionally, the primary
+ * primitive ids of the last one). flatten = 0: two-level traversal on the GPU (one BVH per model); 1: the instances
+ * copied into one world-space model. `moved` (optional, n_instances entries): transforms applied after the build
+ * through Renderer::updateInstances (the top level's updateOnly path). Needs a GPU. */
+int prth_render_instances(const prth_model* const* models, size_t n_models, const prth_instance* instances,
+                          size_t n_instances, int flatten, int device, uint32_t width, uint32_t height,
+                          const prth_settings* settings, const float eye[3], const float target[3], const float* light_pos,
+                          const float* light_dir, uint32_t first_iteration, uint32_t n_iterations,
+                          const prth_instance* moved, float* accum_out, uint32_t* hit_ids_out, char* err, size_t err_len);
 /* Same as prth_render_obj for an already loaded (or flattened) model, with a camera-captured light or an
  * AreaLight; `resume_from` / `save_to` (optional paths) restore / store the progressive state around the n
  * iterations (Renderer::loadCheckpoint / saveCheckpoint). Needs a GPU. */

@@ -66,11 +66,32 @@ void Renderer::initRaytracing(const std::vector<Model>& models)
     check(prt_build_accel(m_ctx), "prt_build_accel");
 }
 
-void Renderer::initRaytracing(const std::vector<Model>& models, const std::vector<Instance>& instances)
+void Renderer::initRaytracing(const std::vector<Model>& models, const std::vector<Instance>& instances, bool flatten)
 {
-    const FlatScene          fs = flattenInstances(models, instances);
-    const std::vector<Model> one(1, fs.model);
-    initRaytracing(one);
+    if(flatten)
+    {
+        const FlatScene          fs = flattenInstances(models, instances);
+        const std::vector<Model> one(1, fs.model);
+        initRaytracing(one);
+        return;
+    }
+    const PooledScene        ps = poolInstances(models, instances);
+    const Model&             m  = ps.model;
+    std::vector<prt_texture> tex;
+    for(const Texture& t : m.m_textures) tex.push_back(prt_texture{t.image.rgba.data(), t.width, t.height});
+    check(prt_set_scene(m_ctx, m.m_vertices.data(), m.m_vertices.size(), m.m_indices.data(), m.m_indices.size(),
+                        m.m_materials.data(), m.m_materials.size(), tex.data(), tex.size()),
+          "prt_set_scene");
+    check(prt_set_instances(m_ctx, ps.ranges.data(), ps.ranges.size(), ps.instances.data(), ps.instances.size()),
+          "prt_set_instances");
+    check(prt_build_accel(m_ctx), "prt_build_accel");
+}
+
+void Renderer::updateInstances(const std::vector<Instance>& instances)
+{
+    std::vector<float> xf(instances.size() * 16);
+    for(size_t i = 0; i < instances.size(); ++i) memcpy(&xf[16 * i], instances[i].transform.data(), 64);
+    check(prt_update_instance_transforms(m_ctx, xf.data(), instances.size()), "prt_update_instance_transforms");
 }
 
 void Renderer::updateVertices(const std::vector<VertexPNTC>& vertices)

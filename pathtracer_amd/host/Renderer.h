@@ -46,8 +46,11 @@ public:
 
     // VkRTX::initRaytracing(gpu, models, ubo, uboMem): models[0] only (vkRTX_setup.cpp:67, 459)
     void initRaytracing(const std::vector<Model>& models);
-    // several models / instances (vkRT_TLAS.cpp:58-72 AddInstance), flattened on the host: see Scene.h
-    void initRaytracing(const std::vector<Model>& models, const std::vector<Instance>& instances);
+    // several models / instances (vkRT_TLAS.cpp:58-72 AddInstance): one BVH per model + a top level over the instances
+    // on the GPU (prt_set_instances); flatten = true copies the instances into one world-space model instead (Scene.h)
+    void initRaytracing(const std::vector<Model>& models, const std::vector<Instance>& instances, bool flatten = false);
+    // vkRT_TLAS.cpp:178-279 with updateOnly = true: new transforms for the instances of the last initRaytracing
+    void updateInstances(const std::vector<Instance>& instances);
     // vkRT_BLAS.cpp:209-290 / vkRT_TLAS.cpp:178-279 with updateOnly = true: same topology, moved vertices
     void updateVertices(const std::vector<VertexPNTC>& vertices);
 

@@ -25,14 +25,11 @@ static vec3 mulDir(const mat4& m, const vec3& v)
                 m[0][2] * v.x + m[1][2] * v.y + m[2][2] * v.z);
 }
 
-FlatScene flattenInstances(const std::vector<Model>& models, const std::vector<Instance>& instances)
+// merged material / texture tables, in model order
+static void mergeTables(const std::vector<Model>& models, Model& dst, std::vector<int32_t>& matBase)
 {
-    if(models.empty()) throw std::runtime_error("flattenInstances: no model");
-    if(instances.empty()) throw std::runtime_error("flattenInstances: no instance");
-    FlatScene out;
-    Model&    dst = out.model;
-    // merged material / texture tables, in model order
-    std::vector<int32_t> matBase(models.size()), texBase(models.size());
+    std::vector<int32_t> texBase(models.size());
+    matBase.resize(models.size());
     for(size_t k = 0; k < models.size(); ++k)
     {
         const Model& m = models[k];
@@ -54,6 +51,51 @@ FlatScene flattenInstances(const std::vector<Model>& models, const std::vector<I
         if(!m.warnings.empty()) dst.warnings += m.warnings;
     }
     dst.directory = models[0].directory;
+}
+
+PooledScene poolInstances(const std::vector<Model>& models, const std::vector<Instance>& instances)
+{
+    if(models.empty()) throw std::runtime_error("poolInstances: no model");
+    if(instances.empty()) throw std::runtime_error("poolInstances: no instance");
+    PooledScene          out;
+    Model&               dst = out.model;
+    std::vector<int32_t> matBase;
+    mergeTables(models, dst, matBase);
+    for(size_t k = 0; k < models.size(); ++k)
+    {
+        const Model&   m    = models[k];
+        const uint32_t base = (uint32_t)dst.m_vertices.size();
+        out.ranges.push_back(prt_blas_range{(uint32_t)(dst.m_indices.size() / 3), (uint32_t)(m.m_indices.size() / 3)});
+        for(VertexPNTC v : m.m_vertices)
+        {
+            v.materialID += matBase[k];
+            dst.m_vertices.push_back(v);
+        }
+        for(uint32_t i : m.m_indices) dst.m_indices.push_back(base + i);
+    }
+    for(const Instance& inst : instances)
+    {
+        if(inst.modelIndex >= models.size()) throw std::runtime_error("poolInstances: modelIndex out of range");
+        prt_instance pi{};
+        memcpy(pi.transform, inst.transform.data(), 64);
+        pi.blas        = inst.modelIndex;
+        pi.instance_id = inst.instanceId;
+        pi.hit_group   = inst.hitGroupIndex;
+        out.instances.push_back(pi);
+    }
+    dst.numVertices = dst.m_vertices.size();
+    dst.numIndices  = dst.m_indices.size();
+    return out;
+}
+
+FlatScene flattenInstances(const std::vector<Model>& models, const std::vector<Instance>& instances)
+{
+    if(models.empty()) throw std::runtime_error("flattenInstances: no model");
+    if(instances.empty()) throw std::runtime_error("flattenInstances: no instance");
+    FlatScene            out;
+    Model&               dst = out.model;
+    std::vector<int32_t> matBase;
+    mergeTables(models, dst, matBase);
     for(const Instance& inst : instances)
     {
         if(inst.modelIndex >= models.size()) throw std::runtime_error("flattenInstances: modelIndex out of range");

@@ -280,6 +280,83 @@ int prth_flatten_instances(const prth_model* const* models, size_t nModels, cons
     }
 }
 
+static void to_scene(const prth_model* const* models, size_t nModels, const prth_instance* instances, size_t nInst,
+                     std::vector<Model>& ms, std::vector<Instance>& is)
+{
+    for(size_t i = 0; i < nModels; ++i)
+    {
+        if(!models[i]) throw std::runtime_error("null model");
+        ms.push_back(models[i]->m);
+    }
+    is.resize(nInst);
+    for(size_t i = 0; i < nInst; ++i)
+    {
+        is[i].modelIndex = instances[i].modelIndex;
+        memcpy(&is[i].transform[0][0], instances[i].transform, 64);
+        is[i].instanceId    = instances[i].instanceId;
+        is[i].hitGroupIndex = instances[i].hitGroupIndex;
+    }
+}
+
+int prth_pool_instances(const prth_model* const* models, size_t nModels, const prth_instance* instances, size_t nInst,
+                        prth_model** out, prt_blas_range* ranges, prt_instance* instOut, char* err, size_t errLen)
+{
+    if(!models || !instances || !out) return -1;
+    try
+    {
+        std::vector<Model>    ms;
+        std::vector<Instance> is;
+        to_scene(models, nModels, instances, nInst, ms, is);
+        PooledScene ps = poolInstances(ms, is);
+        if(ranges) memcpy(ranges, ps.ranges.data(), ps.ranges.size() * sizeof(prt_blas_range));
+        if(instOut) memcpy(instOut, ps.instances.data(), ps.instances.size() * sizeof(prt_instance));
+        *out = new prth_model{std::move(ps.model)};
+        return 0;
+    }
+    catch(const std::exception& e)
+    {
+        set_err(err, errLen, e.what());
+        return -2;
+    }
+}
+
+int prth_render_instances(const prth_model* const* models, size_t nModels, const prth_instance* instances, size_t nInst,
+                          int flatten, int device, uint32_t w, uint32_t h, const prth_settings* settings, const float eye[3],
+                          const float target[3], const float* lightPos, const float* lightDir, uint32_t first, uint32_t n,
+                          const prth_instance* moved, float* accumOut, uint32_t* hitIdsOut, char* err, size_t errLen)
+{
+    if(!models || !instances || !eye || !target || !accumOut) return -1;
+    try
+    {
+        std::vector<Model>    ms;
+        std::vector<Instance> is;
+        to_scene(models, nModels, instances, nInst, ms, is);
+        Renderer r(device, w, h);
+        setup_view(r, settings, w, h, eye, target, lightPos, lightDir);
+        r.initRaytracing(ms, is, flatten != 0);
+        if(moved)
+        {
+            std::vector<Model>    dummy;
+            std::vector<Instance> is2;
+            to_scene(models, 0, moved, nInst, dummy, is2);
+            if(flatten)
+                r.initRaytracing(ms, is2, true);
+            else
+                r.updateInstances(is2);
+        }
+        r.render(first, n, 1);
+        const std::vector<float> a = r.readAccum();
+        memcpy(accumOut, a.data(), a.size() * sizeof(float));
+        if(hitIdsOut && prt_read_hit_ids(r.context(), hitIdsOut) != PRT_OK) throw std::runtime_error(prt_last_error(r.context()));
+        return 0;
+    }
+    catch(const std::exception& e)
+    {
+        set_err(err, errLen, e.what());
+        return -2;
+    }
+}
+
 int prth_render_model(const prth_model* model, int device, uint32_t w, uint32_t h, const prth_settings* settings,
                       const float eye[3], const float target[3], const float* lightPos, const float* lightDir, uint32_t first,
                       uint32_t n, const char* resumeFrom, const char* saveTo, float* accumOut, char* err, size_t errLen)

@@ -19,6 +19,7 @@ int main(int argc, char** argv)
                 "          [--eye x y z] [--target x y z] [--light x y z dx dy dz] [--light-area A] [--light-e E]\n"
                 "          [--ao-rays N] [--ao-length L] [--device D] [--out image.ppm] [--pfm image.pfm] [--png image.png]\n"
                 "          [--model more.obj]... [--instance MODEL x y z scale]... (default: one identity instance of model 0)\n"
+                "          [--flatten]  (copy the instances into one world-space model instead of two-level traversal)\n"
                 "          [--resume state.ckpt] [--checkpoint state.ckpt]  (continue / save the progressive render)\n",
                 argv[0]);
         return 2;
@@ -27,7 +28,7 @@ int main(int argc, char** argv)
     int         device = 0;
     Settings    s;
     vec3        eye(0, 1, 3), target(0, 1, 0), lpos, ldir;
-    bool        haveLight = false;
+    bool        haveLight = false, flatten = false;
     std::string out = "out.ppm", pfm, png, resume, checkpoint;
     std::vector<std::string> extraModels;
     std::vector<Instance>    instances;
@@ -61,6 +62,7 @@ int main(int argc, char** argv)
         else if(!strcmp(argv[i], "--resume")) { need(1); resume = argv[++i]; }
         else if(!strcmp(argv[i], "--checkpoint")) { need(1); checkpoint = argv[++i]; }
         else if(!strcmp(argv[i], "--model")) { need(1); extraModels.push_back(argv[++i]); }
+        else if(!strcmp(argv[i], "--flatten")) flatten = true;
         else if(!strcmp(argv[i], "--instance"))
         {
             need(5);
@@ -114,8 +116,10 @@ int main(int argc, char** argv)
                     in.instanceId = (uint32_t)k;
                     instances.push_back(in);
                 }
-            ntri = flattenInstances(models, instances).model.m_indices.size() / 3;
-            r.initRaytracing(models, instances);
+            ntri = 0;
+            for(const Instance& in : instances)
+                if(in.modelIndex < models.size()) ntri += models[in.modelIndex].m_indices.size() / 3;
+            r.initRaytracing(models, instances, flatten);
         }
         uint32_t first = 1;
         if(!resume.empty())

@@ -18,6 +18,7 @@ EXPORTS = [
     "prth_model_materials", "prth_model_texture", "prth_model_warnings", "prth_obj_dump_json", "prth_image_load",
     "prth_free", "prth_default_settings", "prth_camera_uniforms", "prth_render_obj", "prth_flatten_instances",
     "prth_render_model", "prth_write_png", "prth_checkpoint_write", "prth_checkpoint_read", "prth_frame_loop",
+    "prth_pool_instances", "prth_render_instances",
 ]
 
 EVENT_MOVE_CAMERA, EVENT_MOVE_LIGHT, EVENT_SET_MODE = 0, 1, 2
@@ -77,6 +78,10 @@ def lib():
                                       C.c_uint32, C.c_uint32, vp, vp, C.c_char_p, sz]
         L.prth_flatten_instances.argtypes = [C.POINTER(vp), sz, C.POINTER(_Instance), sz, C.POINTER(vp),
                                              C.POINTER(C.c_uint32), C.c_char_p, sz]
+        L.prth_pool_instances.argtypes = [C.POINTER(vp), sz, C.POINTER(_Instance), sz, C.POINTER(vp), vp, vp, C.c_char_p, sz]
+        L.prth_render_instances.argtypes = [C.POINTER(vp), sz, C.POINTER(_Instance), sz, C.c_int, C.c_int, C.c_uint32,
+                                            C.c_uint32, C.POINTER(Settings), fp, fp, fp, fp, C.c_uint32, C.c_uint32,
+                                            C.POINTER(_Instance), vp, vp, C.c_char_p, sz]
         L.prth_render_model.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(Settings), fp, fp, fp, fp,
                                         C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, vp, C.c_char_p, sz]
         L.prth_frame_loop.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(Settings), fp, fp, vp, sz, C.c_uint32, vp,
@@ -172,6 +177,56 @@ def flatten_instances(models, instances):
     if L.prth_flatten_instances(hs, len(models), arr, len(instances), C.byref(out), first, err, len(err)) != 0:
         raise HostError(err.value.decode(errors="replace"))
     return ModelHandle(out, "flattened"), np.array(first[:], np.uint32)
+
+
+def _instance_array(instances):
+    arr = (_Instance * max(1, len(instances)))()
+    for k, (mi, xf, iid) in enumerate(instances):
+        arr[k].modelIndex = mi
+        arr[k].transform[:] = [float(x) for x in np.asarray(xf, np.float32).reshape(16)]
+        arr[k].instanceId = iid
+    return arr
+
+
+def pool_instances(models, instances):
+    """Scene.h poolInstances: (ModelHandle of the object-space pool, BLAS_DTYPE ranges, INSTANCE_DTYPE instances) — the
+    arguments of prt_set_scene + prt_set_instances."""
+    from .scenes import BLAS_DTYPE, INSTANCE_DTYPE
+
+    hs = (C.c_void_p * len(models))(*[m.h for m in models])
+    out = C.c_void_p()
+    ranges = np.zeros(len(models), BLAS_DTYPE)
+    inst = np.zeros(len(instances), INSTANCE_DTYPE)
+    err = C.create_string_buffer(1024)
+    if lib().prth_pool_instances(hs, len(models), _instance_array(instances), len(instances), C.byref(out),
+                                 ranges.ctypes.data_as(C.c_void_p), inst.ctypes.data_as(C.c_void_p), err, len(err)) != 0:
+        raise HostError(err.value.decode(errors="replace"))
+    return ModelHandle(out, "pooled"), ranges, inst
+
+
+def render_instances(models, instances, width, height, settings, eye, target, light=None, first=1, n=1, device=0,
+                     flatten=False, moved=None):
+    """Renderer::initRaytracing(models, instances, flatten) + n iterations: (accum, primary hit ids of the last one).
+    moved: a second instance list whose transforms replace the first after the build (Renderer::updateInstances)."""
+    fp = C.POINTER(C.c_float)
+    a = lambda x: np.asarray(x, np.float32)
+    eye, target = a(eye), a(target)
+    lp = ld = None
+    if light is not None:
+        lp, ld = a(light[0]), a(light[1])
+    hs = (C.c_void_p * len(models))(*[m.h for m in models])
+    accum = np.zeros((height, width, 4), np.float32)
+    ids = np.zeros((height, width), np.uint32)
+    err = C.create_string_buffer(1024)
+    rc = lib().prth_render_instances(hs, len(models), _instance_array(instances), len(instances), 1 if flatten else 0,
+                                     device, width, height, C.byref(settings), eye.ctypes.data_as(fp),
+                                     target.ctypes.data_as(fp), lp.ctypes.data_as(fp) if lp is not None else None,
+                                     ld.ctypes.data_as(fp) if ld is not None else None, first, n,
+                                     _instance_array(moved) if moved is not None else None,
+                                     accum.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), err, len(err))
+    if rc != 0:
+        raise HostError(err.value.decode(errors="replace"))
+    return accum, ids
 
 
 def render_model(model, width, height, settings, eye, target, light=None, first=1, n=1, device=0, resume_from=None,

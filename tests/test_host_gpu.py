@@ -96,6 +96,69 @@ def test_instanced_scene_equals_oracle_on_flattened_arrays(po, tmp_path):
         m.close()
 
 
+def test_device_instancing_through_the_host_layer(po, tmp_path):
+    """Two models, four instances -> Renderer::initRaytracing(models, instances): one geometry pool + prt_set_instances
+    (two-level traversal on the GPU). Bit-exact against the oracle fed with the same pool and instance list; within
+    rounding of the flattened path; Renderer::updateInstances = a fresh build with the new transforms."""
+    (tmp_path / "quad.mtl").write_text("newmtl floor\nKd 0.7 0.7 0.6\nPr 0.4\n")
+    (tmp_path / "quad.obj").write_text("mtllib quad.mtl\nv -4 0 -4\nv 4 0 -4\nv 4 0 4\nv -4 0 4\nvn 0 1 0\nusemtl floor\n"
+                                       "f 1//1 3//1 2//1\nf 1//1 4//1 3//1\n")
+    a = hostapi.open_model(os.path.join(G, "obj", "mixed.obj"))
+    q = hostapi.open_model(str(tmp_path / "quad.obj"))
+    ident = np.eye(4, dtype=np.float32)
+
+    def xf(tx, ty, tz, sc, rot=0.0):
+        c, s_ = np.float32(np.cos(rot)), np.float32(np.sin(rot))
+        M = np.zeros((4, 4), np.float32)
+        M[0] = (c * sc, 0, -s_ * sc, 0)
+        M[1] = (0, sc, 0, 0)
+        M[2] = (s_ * sc, 0, c * sc, 0)
+        M[3] = (tx, ty, tz, 1)
+        return M
+
+    insts = [(1, xf(0, -0.05, 0, 1.0), 0), (0, ident, 1), (0, xf(1.6, 0, -0.8, 0.6, 0.7), 2),
+             (0, xf(-1.5, 0.1, -1.0, 0.8, -1.1), 3)]
+    moved = [(1, xf(0, -0.05, 0, 1.0), 0), (0, xf(0.2, 0, 0.1, 1.1, 0.3), 1), (0, xf(1.2, 0.2, -0.5, 0.7, 1.9), 2),
+             (0, xf(-1.1, 0.0, -1.3, 0.9, 0.4), 3)]
+    W, H = 96, 64
+    s = hostapi.default_settings(numIndicesBounces=3, rtRenderingMode=0, lightSourceArea=0.3)
+    eye, target = (0.3, 1.6, 2.6), (0.0, 0.5, -0.5)
+    light = ((0.0, 3.0, 0.5), (0.0, -1.0, -0.1))
+    ubo = _view_ubo(W, H, s, eye, target, light)
+    pool, ranges, pinst = hostapi.pool_instances([a, q], insts)
+    scene = pool.scene()
+    assert int(ranges["n_triangles"].sum()) == len(scene["indices"]) // 3 and (pinst["blas"] == [1, 0, 0, 0]).all()
+
+    def oracle_image(instances):
+        o = po.Oracle(scene, seed=1)
+        o.set_instances(ranges, instances)
+        acc = np.zeros((H, W, 4), np.float32)
+        for it in (1, 2, 3):
+            u = ubo.copy()
+            u["iteration"] = it
+            acc, ids, _ = o.render(u, W, H, 0, accum=acc, want_ids=True)
+        return acc, ids
+
+    def same(x, y):
+        nan = np.isnan(x)
+        return (nan == np.isnan(y)).all() and np.where(nan, 0, x).tobytes() == np.where(nan, 0, y).tobytes()
+
+    gpu, gids = hostapi.render_instances([a, q], insts, W, H, s, eye, target, light=light, first=1, n=3)
+    acc, ids = oracle_image(pinst)
+    assert (gids == ids).all() and same(gpu, acc)
+    flat, fids = hostapi.render_instances([a, q], insts, W, H, s, eye, target, light=light, first=1, n=3, flatten=True)
+    assert (gids == fids).mean() > 0.999
+    ok = ~(np.isnan(gpu) | np.isnan(flat))
+    assert float(((gpu[ok] - flat[ok]) ** 2).sum() / (flat[ok] ** 2).sum()) < 1e-6
+    # the top level's updateOnly path
+    upd, uids = hostapi.render_instances([a, q], insts, W, H, s, eye, target, light=light, first=1, n=3, moved=moved)
+    _, _, minst = hostapi.pool_instances([a, q], moved)
+    macc, mids = oracle_image(minst)
+    assert (uids == mids).all() and same(upd, macc) and not same(upd, gpu)
+    for m in (a, q, pool):
+        m.close()
+
+
 def test_checkpoint_resume_is_bit_exact(tmp_path):
     m = hostapi.open_model(os.path.join(G, "obj", "mixed.obj"))
     W, H = 64, 48

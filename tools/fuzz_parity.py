@@ -12,8 +12,11 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0, case = time.time(), 0
 while time.time() - t0 < budget:
     case += 1
-    kind = rng.integers(0, 5)
-    if kind == 0:
+    kind = rng.integers(0, 7)
+    if kind >= 5:  # two-level scene: instances with random transforms (prt_set_instances)
+        sc = scenes.instanced_scene(seed=int(rng.integers(1 << 30)), n_instances=int(rng.integers(1, 400 if big else 60)),
+                                    detail=float(rng.uniform(0.3, 2.0)), wild=bool(rng.integers(0, 2)))
+    elif kind == 0:
         sc = scenes.random_soup(int(rng.integers(1, 6000)), seed=int(rng.integers(1 << 30)), extent=float(rng.uniform(0.5, 8)),
                                 size=float(rng.uniform(0.05, 2.0)))
     elif kind == 1:
@@ -58,9 +61,14 @@ while time.time() - t0 < budget:
         print("dumped", desc)
         sys.exit(0)
     o = po.Oracle(sc, seed=seed)
+    if "instances" in sc:
+        o.set_instances(sc["blas"], sc["instances"])
     o.build_bvh()
     ctx = capi.Context(W, H)
-    ctx.set_scene(sc); ctx.set_seed(seed); ctx.build_accel(); ctx.set_flags(flags)
+    ctx.set_scene(sc)
+    if "instances" in sc:
+        ctx.set_instances(sc["blas"], sc["instances"])
+    ctx.set_seed(seed); ctx.build_accel(); ctx.set_flags(flags)
     ctx.set_pipeline_depth(depth); ctx.set_iteration_batch(batch)
     if rng.random() < 0.2:  # the reference's explicit 32-layer scramble image instead of the hash
         table = rng.integers(0, 2 ** 32, (32, H * W), dtype=np.uint64).astype(np.uint32)
@@ -78,6 +86,13 @@ while time.time() - t0 < budget:
     nd = int((g.view(np.uint32) != acc.view(np.uint32)).any(axis=-1).sum())
     gids, grays = ctx.read_hit_ids(), ctx.stats().rays
     ok = nd == 0 and (gids == ids).all() and grays == rays
+    if "instances" in sc:  # random rays against the oracle's brute force over all instances
+        nr = 20000
+        arr = np.zeros(nr, capi.RAY_DTYPE)
+        arr["o"] = rng.uniform(-6, 6, (nr, 3)); arr["d"] = rng.normal(0, 1, (nr, 3)) * rng.uniform(0.01, 10, (nr, 1))
+        arr["tmin"], arr["tmax"] = 1e-6, rng.choice([0.5, 2.0, 1e3], nr)
+        ok = ok and ctx.trace(arr).tobytes() == o.trace_closest(arr, brute=True).tobytes()
+        ok = ok and ((ctx.trace(arr, any_hit=True)["prim"] != 0xFFFFFFFF) == o.trace_any(arr, brute=True).astype(bool)).all()
     if not ok and os.environ.get("FUZZ_DEBUG"):
         # one iteration at a time: which iteration, which pixels, how many rays
         for k in range(n):
