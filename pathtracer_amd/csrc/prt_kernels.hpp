@@ -309,8 +309,11 @@ struct ExtendIO
 #ifndef PRT_TRACE_ATTR
 #define PRT_TRACE_ATTR
 #endif
+#ifndef PRT_TRACE_WAVES_TWO
+#define PRT_TRACE_WAVES_TWO 5  // waves per SIMD of the two-level traversal kernels (96 VGPRs; measured 4: 3470, 5: 3730, 6: 3280 Mrays/s)
+#endif
 template <bool INSTR, bool TWO = false>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, (INSTR || TWO) ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_extend(SceneView sc, FrameView f, uint32_t generation,
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : (TWO ? PRT_TRACE_WAVES_TWO : PRT_TRACE_WAVES)) PRT_TRACE_ATTR k_extend(SceneView sc, FrameView f, uint32_t generation,
                                                             const uint32_t* __restrict__ countPtr,
                                                             uint32_t* workCtr, uint32_t primary, TraceTune tune)
 {
@@ -419,11 +422,14 @@ __global__ void __launch_bounds__(256) k_gather_shading(const prt_vertex* __rest
     o[6] = make_float4(__int_as_float(verts[idx[3 * i + 1]].materialID), 0.0f, 0.0f, 0.0f);
 }
 
+#ifndef PRT_SHADE_WAVES_TWO
+#define PRT_SHADE_WAVES_TWO 4  // two-level scenes (2: 20.3 ms, 4: 19.3 ms per pass)
+#endif
 #ifndef PRT_SHADE_WAVES
 #define PRT_SHADE_WAVES 4  // 128 VGPRs, no scratch; 5 or 6 spill and are slower, 2-3 leave the compiler 132 VGPRs = 3 waves per SIMD
 #endif
 template <bool TWO = false>
-__global__ void __launch_bounds__(256, TWO ? 2 : PRT_SHADE_WAVES) k_shade(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,
+__global__ void __launch_bounds__(256, TWO ? PRT_SHADE_WAVES_TWO : PRT_SHADE_WAVES) k_shade(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,
                                                uint32_t bounce, const uint32_t* __restrict__ countIn,
                                                uint32_t* countNext, uint32_t* countShadow)
 {
@@ -795,7 +801,7 @@ struct ShadowIO
 };
 
 template <bool INSTR, bool TWO = false>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, (INSTR || TWO) ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow(SceneView sc, FrameView f,
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : (TWO ? PRT_TRACE_WAVES_TWO : PRT_TRACE_WAVES)) PRT_TRACE_ATTR k_shadow(SceneView sc, FrameView f,
                                                             const uint32_t* __restrict__ countPtr, uint32_t* workCtr,
                                                             uint32_t bounce, TraceTune tune)
 {
@@ -813,7 +819,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, (INSTR || TWO) ? 4 : PRT_TRAC
 // the shadow queue, so the few long rays at the end of the first stream run beside the second stream instead of on
 // an empty GPU — one launch tail per bounce instead of two.
 template <bool INSTR, bool TWO = false>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, (INSTR || TWO) ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_shadow_extend(
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : (TWO ? PRT_TRACE_WAVES_TWO : PRT_TRACE_WAVES)) PRT_TRACE_ATTR k_shadow_extend(
     SceneView sc, FrameView f, const uint32_t* __restrict__ shCountPtr, uint32_t* shWork, uint32_t bounce,
     const uint32_t* __restrict__ exCountPtr, uint32_t* exWork, TraceTune tune)
 {
@@ -1011,7 +1017,7 @@ struct BatchIO
     }
 };
 template <bool ANY, bool TWO = false>
-__global__ void __launch_bounds__(PRT_TRACE_BLOCK, TWO ? 4 : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_trace_batch(BvhView bvh, const float4* __restrict__ rays,
+__global__ void __launch_bounds__(PRT_TRACE_BLOCK, TWO ? PRT_TRACE_WAVES_TWO : PRT_TRACE_WAVES) PRT_TRACE_ATTR k_trace_batch(BvhView bvh, const float4* __restrict__ rays,
                                                                  uint32_t n, float4* __restrict__ hits,
                                                                  uint32_t* workCtr, TraceTune tune,
                                                                  unsigned long long* stats)

@@ -136,9 +136,12 @@ PRT_DEV void ray_prepare(const BvhView& bvh, f3 o, float tmin, f3 d, float tmax,
     // so t = T/det, u = V/det, v = W/det and the sign tests come out bit-identical without it.
     const float dkz = sel3(d.x, d.y, d.z, kz);
     r.kz = kz;
-    r.Sx = sel3(d.x, d.y, d.z, kx) / dkz;
-    r.Sy = sel3(d.x, d.y, d.z, ky) / dkz;
-    r.Sz = 1.0f / dkz;
+    if(!TOP)  // the top level of a two-level scene holds no triangles: the shear is set when an instance is entered
+    {
+        r.Sx = sel3(d.x, d.y, d.z, kx) / dkz;
+        r.Sy = sel3(d.x, d.y, d.z, ky) / dkz;
+        r.Sz = 1.0f / dkz;
+    }
     float amax = bvh.sceneAbs;
     amax       = gmax(amax, gabs(o.x));
     amax       = gmax(amax, gabs(o.y));
@@ -496,7 +499,7 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, f3 o, float tmin, f3 d,
 // IO::store(tag, hit) is called once per ray when it has finished.
 // TWO: two-level scene. A lane at the top level that reaches a leaf (= an instance) enters it at the next node step;
 // a lane that pops the exit marker leaves the instance once its postponed leaf (which belongs to the instance) has
-// been tested. The world-space ray is read again from the queue (io.load is a pure function of the slot).
+// been tested. The world-space ray stays in six registers (the TWO kernels run at 4 waves per SIMD and have them).
 template <bool ANY, bool INSTR, class IO, bool TWO = false>
 PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uint32_t* workCtr, const TraceTune tune,
                           IO& io, uint32_t& nskipped, TraceCount& tc)
@@ -516,6 +519,8 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
     float                    curAbs   = bvh.sceneAbs;
     uint32_t                 primBase = 0;
     bool                     inInst   = false;
+    f3                       wo = mk3(0.0f), wd = mk3(0.0f);  // the ray in world space
+    float                    wtmin = 0.0f;                    // (r.tmin may have been closed by a NaN in object space)
     constexpr int32_t        kStepEnd = TWO ? kInstExit : kSentinel;  // references below this are inner nodes
     r.tmin = r.tmax = 0.0f;
     PRT_STACK_AT(lds, 0) = (uint32_t)kSentinel;  // bottom of the lane's stack; sp >= 1 always
@@ -569,7 +574,13 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
                 leaf   = kEmptyLeaf;
                 sp     = 1;
                 active = true;
-                if(TWO) inInst = false;
+                if(TWO)
+                {
+                    inInst = false;
+                    wo     = o;
+                    wd     = d;
+                    wtmin  = tmin;
+                }
             }
             chunkPos += take;
         }
@@ -589,35 +600,6 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
         //      it and keeps descending; lanes at a second leaf (or finished) wait
         for(;;)
         {
-            if(TWO && active)
-            {
-                if(cur == kInstExit && leaf == kEmptyLeaf)
-                {
-                    f3       o, d;
-                    float    tmin, tmax;
-                    uint32_t tg;
-                    io.load(tag, o, tmin, d, tmax, tg);
-                    ray_prepare<true>(bvh, o, tmin, d, tmax, r);
-                    inInst = false;
-                    cur    = stack_pop(sp, lds, spill);
-                }
-                if(cur < 0 && !inInst)
-                {
-                    f3       o, d;
-                    float    tmin, tmax;
-                    uint32_t tg;
-                    io.load(tag, o, tmin, d, tmax, tg);
-                    const int32_t root = instance_enter(bvh, cur, o, tmin, d, tmax, r, curAbs, primBase);
-                    if(root == kEmptyLeaf)
-                        cur = stack_pop(sp, lds, spill);
-                    else
-                    {
-                        stack_push_slow(sp, lds, spill, kInstExit);
-                        inInst = true;
-                        cur    = root;
-                    }
-                }
-            }
             if(INSTR)
             {
                 const uint32_t n = (uint32_t)__popcll(__ballot(active && (uint32_t)cur < (uint32_t)kStepEnd));
@@ -637,10 +619,9 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
                     cur  = stack_pop(sp, lds, spill);
                 }
             }
-            // lanes that can go on in this phase: at an inner node, or (two-level) about to enter / leave an instance
-            const bool prod = active && ((uint32_t)cur < (uint32_t)kStepEnd ||
-                                         (TWO && ((cur == kInstExit && leaf == kEmptyLeaf) || (cur < 0 && !inInst))));
-            const uint32_t nProd = (uint32_t)__popcll(__ballot(prod));
+            // lanes that can go on in this phase: at an inner node (two-level: lanes about to enter or leave an instance
+            // wait for the transition phase below, like lanes at a second leaf wait for the triangle phase)
+            const uint32_t nProd = (uint32_t)__popcll(__ballot(active && (uint32_t)cur < (uint32_t)kStepEnd));
             if(nProd == 0 || nActive - nProd > tune.stallMax) break;
         }
 
@@ -686,6 +667,30 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
                 {
                     leaf = cur;
                     cur  = stack_pop(sp, lds, spill);
+                }
+            }
+        }
+
+        // ---- two-level scenes: instance boundaries, for all lanes that wait at one (leave, then possibly enter the next)
+        if(TWO && active)
+        {
+            // r.tmax is the ray's own in every space
+            if(cur == kInstExit && leaf == kEmptyLeaf)
+            {
+                ray_prepare<true>(bvh, wo, wtmin, wd, r.tmax, r);
+                inInst = false;
+                cur    = stack_pop(sp, lds, spill);
+            }
+            if(cur < 0 && !inInst)
+            {
+                const int32_t root = instance_enter(bvh, cur, wo, wtmin, wd, r.tmax, r, curAbs, primBase);
+                if(root == kEmptyLeaf)
+                    cur = stack_pop(sp, lds, spill);
+                else
+                {
+                    stack_push_slow(sp, lds, spill, kInstExit);
+                    inInst = true;
+                    cur    = root;
                 }
             }
         }
