@@ -250,6 +250,9 @@ prt_context* prt_group_context(prt_group* g, int member); /* for per-member call
 int prt_group_set_scene(prt_group* g, const prt_vertex* vertices, size_t n_vertices, const uint32_t* indices,
                         size_t n_indices, const prt_material* materials, size_t n_materials,
                         const prt_texture* textures, size_t n_textures);
+/* prt_set_instances + prt_build_accel on every member (after prt_group_set_scene) */
+int prt_group_set_instances(prt_group* g, const prt_blas_range* blas, size_t n_blas, const prt_instance* instances,
+                            size_t n_instances);
 int prt_group_set_scramble_seed(prt_group* g, uint32_t seed);
 int prt_group_set_uniforms(prt_group* g, const prt_uniforms* ubo);
 int prt_group_set_flags(prt_group* g, uint32_t flags);

@@ -29,6 +29,7 @@ EXPORTS = [
     "prt_group_context", "prt_group_set_scene", "prt_group_set_scramble_seed", "prt_group_set_uniforms",
     "prt_group_set_flags", "prt_group_clear_accum", "prt_group_render", "prt_group_reduce", "prt_group_read_accum",
     "prt_group_get_stats", "prt_set_instances", "prt_update_instance_transforms", "prt_read_blas_bvh",
+    "prt_group_set_instances",
 ]
 
 K_GENERATE, K_EXTEND, K_SHADE, K_SHADOW, K_AO_SHADE, K_RESOLVE, K_SHADOW_EXTEND, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 8
@@ -121,6 +122,7 @@ def lib():
         L.prt_group_context.argtypes = [vp, i32]
         L.prt_group_context.restype = vp
         L.prt_group_set_scene.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz]
+        L.prt_group_set_instances.argtypes = [vp, vp, sz, vp, sz]
         L.prt_group_set_scramble_seed.argtypes = [vp, u32]
         L.prt_group_set_uniforms.argtypes = [vp, vp]
         L.prt_group_set_flags.argtypes = [vp, u32]
@@ -387,6 +389,11 @@ class Group:
             arr[k].height, arr[k].width = t.shape[0], t.shape[1]
         self._chk(self.L.prt_group_set_scene(self.h_, _ptr(v), len(v), _ptr(i), len(i), _ptr(m), len(m),
                                              C.addressof(arr), len(texs)))
+
+    def set_instances(self, blas, instances):
+        b = np.ascontiguousarray(blas, dtype=BLAS_DTYPE)
+        i = np.ascontiguousarray(instances, dtype=INSTANCE_DTYPE)
+        self._chk(self.L.prt_group_set_instances(self.h_, _ptr(b), len(b), _ptr(i), len(i)))
 
     def set_seed(self, seed):
         self._chk(self.L.prt_group_set_scramble_seed(self.h_, seed))

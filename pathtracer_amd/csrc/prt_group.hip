@@ -207,6 +207,14 @@ int prt_group_set_scene(prt_group* g, const prt_vertex* v, size_t nv, const uint
         return rc ? rc : prt_build_accel(g->ctx[(size_t)i]);
     });
 }
+int prt_group_set_instances(prt_group* g, const prt_blas_range* blas, size_t nblas, const prt_instance* inst, size_t ninst)
+{
+    if(!g) return PRT_E_INVALID;
+    return for_members(g, [&](int i) {
+        const int rc = prt_set_instances(g->ctx[(size_t)i], blas, nblas, inst, ninst);
+        return rc ? rc : prt_build_accel(g->ctx[(size_t)i]);
+    });
+}
 int prt_group_set_scramble_seed(prt_group* g, uint32_t seed)
 {
     if(!g) return PRT_E_INVALID;

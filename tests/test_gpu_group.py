@@ -63,6 +63,34 @@ def test_group_on_one_device_equals_member_sums(members):
     g.close()
 
 
+def test_group_with_instances_equals_single_context():
+    """prt_group_set_instances: a two-level scene on every member; the sharded sum differs from one context's render by
+    the fp32 summation order only."""
+    sc = scenes.instanced_scene(seed=23, n_instances=12, wild=True)
+    W, H = 64, 48
+    u = uniforms.make_uniforms(sc, W, H, iteration=1, bounces=3)
+    g = capi.Group([0, 0], W, H)
+    g.set_scene(sc)
+    g.set_instances(sc["blas"], sc["instances"])
+    g.set_seed(5)
+    g.set_uniforms(u)
+    g.render(capi.MODE_PATH, 1, 6)
+    g.reduce(0)
+    got = g.read_accum(0)
+    c = capi.Context(W, H)
+    c.set_scene(sc)
+    c.set_instances(sc["blas"], sc["instances"])
+    c.set_seed(5)
+    c.build_accel()
+    c.set_uniforms(u)
+    c.render(capi.MODE_PATH, 1, 6)
+    whole = c.read_accum()
+    assert g.stats().rays == c.stats().rays
+    c.close()
+    g.close()
+    assert np.allclose(got, whole, rtol=3e-6, atol=1e-6) and (got[..., 3] == whole[..., 3]).all()
+
+
 def test_group_reduce_to_other_root_and_errors():
     sc = scenes.cornell_box()
     W, H = 48, 32
