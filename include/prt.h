@@ -167,7 +167,8 @@ int prt_set_pipeline_depth(prt_context* ctx, int n);
 int prt_get_pipeline_depth(const prt_context* ctx); /* current depth (default: 3 when the process has >= 8 HIP
                                                        hardware queues, GPU_MAX_HW_QUEUES, else 2) */
 /* prt_render additionally puts up to `n` consecutive iterations (1..64) into ONE pass over n*W*H "pixels" when
- * the frame is small (default: about 32 M pixels per pass, at most 16 iterations), because a launch's fixed tail does
+ * the frame is small (default: about 128 M pixels per pass, at most 64 iterations; passes of 24 M pixels or more run
+ * one after the other on one stream, smaller ones rotate over the pipeline's streams), because a launch's fixed tail does
  * not grow with its size. Same image, bit for bit; the per-pass buffers grow n-fold. prt_render_iteration is not
  * affected. No counterpart in the reference. */
 int prt_set_iteration_batch(prt_context* ctx, int n);

@@ -383,13 +383,14 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
             if(nb >= 1 && nb <= 16) c->gridShade = (uint32_t)nb * (uint32_t)c->numCU;
         }
         if(const char* fe = getenv("PRT_FUSE")) c->fuse = atoi(fe) != 0;
-        // default batch: enough iterations to put ~64 M pixels into a pass (32 at 1080p, 8 at 4K), at most 32: a launch's
+        // default batch: enough iterations to put ~128 M pixels into a pass (64 at 1080p, 16 at 4K), at most 64: a launch's
         // tail (its longest rays on an emptying GPU) is paid once per pass. Measured at 1080p, Mrays/s with one pass in
-        // flight: 2: 5790, 4: 6840, 8: 7530, 16: 7920, 32: 8100, 64: 8220 (19 GB of path state per pipe at 32).
+        // flight: 2: 5790, 4: 6840, 8: 7530, 16: 7920, 32: 8170, 64: 8280 (38 GB of path state at 64, on one pipe: see
+        // prt_render).
         {
-            const uint64_t target = 64ull << 20;
+            const uint64_t target = 128ull << 20;
             uint64_t       b      = (target + c->npix / 2) / c->npix;
-            c->batch              = (uint32_t)(b < 1 ? 1 : (b > 32 ? 32 : b));
+            c->batch              = (uint32_t)(b < 1 ? 1 : (b > 64 ? 64 : b));
             if(const char* be = getenv("PRT_BATCH"))
             {
                 const int v = atoi(be);
@@ -1267,19 +1268,19 @@ static int pipe_ensure(prt_context* c, Pipe& p, size_t npass, int B)
     return PRT_OK;
 }
 
-static int render_path_pass(prt_context* c, int pi, int aa, uint32_t nsub = 1, uint32_t iterStride = 1)
+static int render_path_pass(prt_context* c, int pi, int aa, uint32_t nsub = 1, uint32_t iterStride = 1, bool rotate = true)
 {
     Pipe&        p     = c->pipes[pi];
     const size_t npass = (size_t)c->npix * nsub;  // "pixels" of this pass: nsub iterations side by side
     const int    B     = c->ubo.numIndirectBounces;
     // all pipes of the rotation at once: an allocation synchronises the device, so it must not happen in the middle
     // of a render (the first pass on pipe 0 would otherwise run alone, then wait for pipe 1's buffers, ...)
-    for(int q = 0; q < c->nPipes; ++q)
+    for(int q = 0; rotate && q < c->nPipes; ++q)
     {
         const int rc = pipe_ensure(c, c->pipes[q], npass, B);
         if(rc) return rc;
     }
-    if(pi >= c->nPipes)
+    if(!rotate || pi >= c->nPipes)
     {
         const int rc = pipe_ensure(c, p, npass, B);
         if(rc) return rc;
@@ -1435,9 +1436,13 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
             if((uint64_t)c->npix * nsub >= (1ull << 31)) nsub = (uint32_t)(((1ull << 31) - 1) / c->npix);  // 32-bit pixel ids
             if(nsub < 2) break;
             c->ubo.iteration    = first + k * stride;
-            const int rc        = render_path_pass(c, c->nextPipe, 0, nsub, stride);
+            // A large pass fills the GPU by itself: passes in flight on other streams add nothing then (measured at
+            // 1080p, 32 / 64 iterations per pass: 8170 / 8280 Mrays/s on one pipe, 8120 / 8250 on three), so such
+            // passes all run on pipe 0 and only that pipe's buffers grow to the pass size.
+            const bool large = (uint64_t)c->npix * nsub >= (24ull << 20);
+            const int  rc    = render_path_pass(c, large ? 0 : c->nextPipe, 0, nsub, stride, !large);
             if(rc) return rc;
-            c->nextPipe = (c->nextPipe + 1) % c->nPipes;
+            if(!large) c->nextPipe = (c->nextPipe + 1) % c->nPipes;
             c->iterations += nsub;
             k += nsub;
         }
