@@ -1158,6 +1158,15 @@ static void fill_bvh_view(const prt_context* c, BvhView& b)
     }
     b.inst     = c->dInst;
     b.padScale = c->padScale;
+    {
+        uint64_t inner = c->top.nInner;  // the node array starts with the top(-level) tree's nodes, level by level
+        static const uint32_t topMax = [] {
+            uint32_t v = PRT_TOP_NODES;
+            if(const char* e = getenv("PRT_TOP")) v = (uint32_t)atoi(e) < v ? (uint32_t)atoi(e) : v;  // measurement only
+            return v;
+        }();
+        b.nTop = (uint32_t)(inner < topMax ? inner : topMax);
+    }
 }
 
 static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& f, uint32_t nsub = 1, uint32_t iterStride = 1)

@@ -317,12 +317,13 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : (TWO ? PRT_TRACE_
                                                             const uint32_t* __restrict__ countPtr,
                                                             uint32_t* workCtr, uint32_t primary, TraceTune tune)
 {
-    __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
+    __shared__ __align__(16) uint32_t stackLds[PRT_TRACE_LDS_WORDS];
+    const uint4* topLds = stage_top_nodes(sc.bvh, stackLds);
     const uint32_t      count = countPtr ? *countPtr : f.npix;
     uint32_t            nskip = 0;
     TraceCount          tc    = {};
     ExtendIO            io(f.gen[generation & 1u], primary ? f.hitIds : nullptr);
-    trace_stream<false, INSTR, ExtendIO, TWO>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nskip, tc);
+    trace_stream<false, INSTR, ExtendIO, TWO>(sc.bvh, &stackLds[threadIdx.x], topLds, count, workCtr, tune, io, nskip, tc);
     flush_counts<INSTR>(f, count, nskip, tc, 0);
 }
 
@@ -805,12 +806,13 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : (TWO ? PRT_TRACE_
                                                             const uint32_t* __restrict__ countPtr, uint32_t* workCtr,
                                                             uint32_t bounce, TraceTune tune)
 {
-    __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
+    __shared__ __align__(16) uint32_t stackLds[PRT_TRACE_LDS_WORDS];
+    const uint4* topLds = stage_top_nodes(sc.bvh, stackLds);
     const uint32_t      count = *countPtr;
     uint32_t            nskip = 0;
     TraceCount          tc    = {};
     ShadowIO            io{f, f.contrib + (size_t)bounce * f.npix};
-    trace_stream<true, INSTR, ShadowIO, TWO>(sc.bvh, &stackLds[threadIdx.x], count, workCtr, tune, io, nskip, tc);
+    trace_stream<true, INSTR, ShadowIO, TWO>(sc.bvh, &stackLds[threadIdx.x], topLds, count, workCtr, tune, io, nskip, tc);
     flush_counts<INSTR>(f, count, nskip, tc, 1);
 }
 
@@ -823,13 +825,14 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : (TWO ? PRT_TRACE_
     SceneView sc, FrameView f, const uint32_t* __restrict__ shCountPtr, uint32_t* shWork, uint32_t bounce,
     const uint32_t* __restrict__ exCountPtr, uint32_t* exWork, TraceTune tune)
 {
-    __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
+    __shared__ __align__(16) uint32_t stackLds[PRT_TRACE_LDS_WORDS];
+    const uint4* topLds = stage_top_nodes(sc.bvh, stackLds);
     {
         const uint32_t count = *exCountPtr;
         uint32_t       nskip = 0;
         TraceCount     tc    = {};
         ExtendIO       io(f.gen[(bounce + 1u) & 1u], nullptr);
-        trace_stream<false, INSTR, ExtendIO, TWO>(sc.bvh, &stackLds[threadIdx.x], count, exWork, tune, io, nskip, tc);
+        trace_stream<false, INSTR, ExtendIO, TWO>(sc.bvh, &stackLds[threadIdx.x], topLds, count, exWork, tune, io, nskip, tc);
         flush_counts<INSTR>(f, count, nskip, tc, 0);
         if(blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(f.stats + 6, (unsigned long long)count);
     }
@@ -838,7 +841,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : (TWO ? PRT_TRACE_
         uint32_t       nskip = 0;
         TraceCount     tc    = {};
         ShadowIO       io{f, f.contrib + (size_t)bounce * f.npix};
-        trace_stream<true, INSTR, ShadowIO, TWO>(sc.bvh, &stackLds[threadIdx.x], count, shWork, tune, io, nskip, tc);
+        trace_stream<true, INSTR, ShadowIO, TWO>(sc.bvh, &stackLds[threadIdx.x], topLds, count, shWork, tune, io, nskip, tc);
         flush_counts<INSTR>(f, count, nskip, tc, 1);
         if(blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(f.stats + 7, (unsigned long long)count);
     }
@@ -885,7 +888,8 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
                                                               uint32_t flags, uint32_t* workCtr)
 {
     const prt_uniforms* ubo = &ubo_;
-    __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
+    __shared__ __align__(16) uint32_t stackLds[PRT_TRACE_LDS_WORDS];
+    const uint4* topLds = stage_top_nodes(sc.bvh, stackLds);
     const uint32_t      count   = f.npix;
     const int           lane    = threadIdx.x & 63;
     const bool          literal = (flags & PRT_FLAG_LITERAL) != 0;
@@ -952,7 +956,7 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
                     const float hy = r * sn;
                     const float hz = __builtin_sqrtf(gmax(0.0f, 1.0f - hx * hx - hy * hy));
                     const f3    Rd = normalize3(mulM(onb, mk3(hx, hy, hz))) * mk3(aoLen);
-                    const Hit   h  = trace_ray<true, false, TWO>(sc.bvh, &stackLds[threadIdx.x], hitPoint, 0.00001f, Rd, 1.0f);
+                    const Hit   h  = trace_ray<true, false, TWO>(sc.bvh, &stackLds[threadIdx.x], topLds, hitPoint, 0.00001f, Rd, 1.0f);
                     if(h.prim == 0xffffffffu) noHit++;
                 }
                 nrays += (uint32_t)numAO;
@@ -1022,11 +1026,12 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, TWO ? PRT_TRACE_WAVES_TWO : P
                                                                  uint32_t* workCtr, TraceTune tune,
                                                                  unsigned long long* stats)
 {
-    __shared__ uint32_t stackLds[PRT_LDS_STACK * PRT_TRACE_BLOCK];
+    __shared__ __align__(16) uint32_t stackLds[PRT_TRACE_LDS_WORDS];
+    const uint4* topLds = stage_top_nodes(bvh, stackLds);
     uint32_t            nskip = 0;
     TraceCount          tc    = {};
     BatchIO             io{rays, hits};
-    trace_stream<ANY, false, BatchIO, TWO>(bvh, &stackLds[threadIdx.x], n, workCtr, tune, io, nskip, tc);
+    trace_stream<ANY, false, BatchIO, TWO>(bvh, &stackLds[threadIdx.x], topLds, n, workCtr, tune, io, nskip, tc);
     if(tc.overrun && (threadIdx.x & 63) == 0) atomicAdd(stats + 28, 1ull);
 }
 

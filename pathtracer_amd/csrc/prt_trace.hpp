@@ -43,11 +43,22 @@ namespace prt {
 #endif
 #define PRT_SPILL_STACK (100 - PRT_LDS_STACK)
 #define PRT_MAX_DEPTH 64  // depth limit of the binary build tree (=> <= 33 BVH4 levels, <= 100 stack entries)
+#ifndef PRT_TRACE_BLOCK
 #define PRT_TRACE_BLOCK 256
+#endif
 #ifndef PRT_TRACE_WAVES
 #define PRT_TRACE_WAVES 6  // waves per SIMD the traversal kernels are compiled for (78 VGPRs; 6 x 20 KiB of LDS per CU)
 #endif
 #define PRT_NODE_BYTES 64
+// The first PRT_TOP_NODES BVH4 nodes (numbered level by level: the top of the tree) are copied into LDS by every block.
+// More than half of all node visits go there (bench scene: 7.0 of 13.0 per closest-hit ray, 8.4 of 14.5 per any-hit ray in
+// the first 96 nodes), and what the L1 charges for a divergent load is per LANE, hit or miss (tools/ubench_gather.hip
+// modes G / H: lanes that read a hot 85-record set through the L1 cost as much as lanes that miss; from LDS they cost
+// nothing there) — the L1's lane rate is what bounds the node phases.
+#ifndef PRT_TOP_NODES
+#define PRT_TOP_NODES 96  // 6 KiB: 6 blocks x (20 + 6) KiB = 156 of the CU's 160 KiB
+#endif
+#define PRT_TRACE_LDS_WORDS (PRT_LDS_STACK * PRT_TRACE_BLOCK + PRT_TOP_NODES * 16)
 #ifndef PRT_CHUNK
 #define PRT_CHUNK 256u  // rays per work-counter atomic: a device-scope atomic is a round trip to the memory side (64: 7.6 ms per launch, 128: 4.32, 256: 4.20, 512: 4.24, 1024: 4.33; eight per-XCD cursors or a static share of the queue: no better)
 #endif
@@ -72,6 +83,7 @@ struct BvhView
     // structure's, whose leaves are single instances; all structures share `nodes` and `tris`.
     const float4* inst;      // 8 x float4 per instance, in top-level leaf order (InstanceRec below)
     float         padScale;  // widening of the top-level box test: covers the rounding of the object-space transforms
+    uint32_t      nTop;      // nodes 0 .. nTop-1 are staged in LDS by the traversal kernels (<= PRT_TOP_NODES)
 };
 // Instance record, 128 bytes: rows 0-2 world -> object (row i = (W[0][i], W[1][i], W[2][i], W[3][i]) of the
 // column-major inverse transform), row 3 = qmin.xyz | sceneAbs of the bottom-level structure, row 4 = qscale.xyz | root
@@ -276,10 +288,26 @@ PRT_DEV void stack_push_slow(int& sp, uint32_t* lds, int32_t* spill, int32_t v)
 // first). No hit: pop. ANY rays skip the distance sort.
 template <bool ANY>
 PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_t& cur, int& sp, uint32_t* lds,
-                        int32_t* spill)
+                        int32_t* spill, const uint4* top)
 {
-    const uint4* np = (const uint4*)((const char*)bvh.nodes + ((uint32_t)cur << 6));
-    const uint4  bx = np[0], by = np[1], bz = np[2], cq = np[3];
+    uint4 bx, by, bz, cq;
+    if(PRT_TOP_NODES && (uint32_t)cur < bvh.nTop)
+    {
+        // an LDS-typed pointer: ds_read_b128, not a flat load that the compiler would merge with the global one below
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const u32x4* lds_u4;
+        lds_u4      tp = (lds_u4)(uintptr_t)(top + ((uint32_t)cur << 2));
+        const u32x4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
+        bx = make_uint4(a.x, a.y, a.z, a.w);
+        by = make_uint4(b.x, b.y, b.z, b.w);
+        bz = make_uint4(c.x, c.y, c.z, c.w);
+        cq = make_uint4(d.x, d.y, d.z, d.w);
+    }
+    else
+    {
+        const uint4* np = (const uint4*)((const char*)bvh.nodes + ((uint32_t)cur << 6));
+        bx = np[0]; by = np[1]; bz = np[2]; cq = np[3];
+    }
     const float  inf = __builtin_inff();
     // words: .x = min of children 0,1  .y = min of 2,3  .z = max of 0,1  .w = max of 2,3 (16 bits each)
     const uint32_t nx01 = r.negx ? bx.z : bx.x, nx23 = r.negx ? bx.w : bx.y;
@@ -403,6 +431,18 @@ PRT_DEV Hit hit_none(float tmax)
     return h;
 }
 
+// Copies the top of the tree into the block's LDS (behind the stacks) and returns it; all threads of the block call it.
+PRT_DEV const uint4* stage_top_nodes(const BvhView& bvh, uint32_t* ldsBase)
+{
+    uint4* top = (uint4*)(ldsBase + PRT_LDS_STACK * PRT_TRACE_BLOCK);
+    if(PRT_TOP_NODES)
+    {
+        for(uint32_t k = threadIdx.x; k < bvh.nTop * 4u; k += PRT_TRACE_BLOCK) top[k] = bvh.nodes[k];
+        __syncthreads();
+    }
+    return top;
+}
+
 // ---- two-level scenes: entering and leaving an instance ------------------------------------------------
 // The lane's ray in the object space of the instance behind top-level leaf `ref`, its slab constants on that
 // structure's grid; returns the structure's root reference (an empty leaf for an empty slot).
@@ -437,7 +477,8 @@ PRT_DEV int32_t instance_enter(const BvhView& bvh, int32_t ref, f3 o, float tmin
 // ANY = true: terminate-on-first-hit / skip-closest-hit-shader occlusion query (prim != ~0u on hit).
 // INSTR = true additionally counts node visits and triangle tests (profiling level 2).
 template <bool ANY, bool INSTR = false, bool TWO = false>
-PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, f3 o, float tmin, f3 d, float tmax, TraceCount* tcp = nullptr)
+PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, const uint4* top, f3 o, float tmin, f3 d, float tmax,
+                      TraceCount* tcp = nullptr)
 {
     RayCtx r;
     ray_prepare<TWO>(bvh, o, tmin, d, tmax, r);
@@ -478,7 +519,7 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, f3 o, float tmin, f3 d,
         if(cur >= 0)
         {
             if(INSTR) tc.nodes++;
-            node4_step<ANY>(bvh, r, best.t, cur, sp, lds, spill);
+            node4_step<ANY>(bvh, r, best.t, cur, sp, lds, spill, top);
         }
         else
         {
@@ -501,8 +542,8 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, f3 o, float tmin, f3 d,
 // a lane that pops the exit marker leaves the instance once its postponed leaf (which belongs to the instance) has
 // been tested. The world-space ray stays in six registers (the TWO kernels run at 4 waves per SIMD and have them).
 template <bool ANY, bool INSTR, class IO, bool TWO = false>
-PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uint32_t* workCtr, const TraceTune tune,
-                          IO& io, uint32_t& nskipped, TraceCount& tc)
+PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, uint32_t count, uint32_t* workCtr,
+                          const TraceTune tune, IO& io, uint32_t& nskipped, TraceCount& tc)
 {
     const int                lane   = threadIdx.x & 63;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
@@ -612,7 +653,7 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, uint32_t count, uin
             if(active && (uint32_t)cur < (uint32_t)kStepEnd)
             {
                 if(INSTR) tc.nodes++;
-                node4_step<ANY>(bvh, r, best.t, cur, sp, lds, spill);
+                node4_step<ANY>(bvh, r, best.t, cur, sp, lds, spill, top);
                 if(cur < 0 && leaf == kEmptyLeaf && (!TWO || inInst))
                 {
                     leaf = cur;

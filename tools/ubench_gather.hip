@@ -8,6 +8,8 @@
 //   D  like A with 80-byte records and five loads                                      (the 8-wide node visit)
 //   E  like B for 128-byte records: eight lanes per record, eight instructions
 //   F  like A with aligned 128-byte records and eight loads                           (an 8-wide node with 16-bit planes)
+//   G  like A, but 3 lanes in 8 read from the first 85 records only                    (lanes near the root of the tree)
+//   H  like G with those lanes reading their record from a copy in LDS                 (top levels cached in LDS)
 // Records come from a table of `tableMB` megabytes; indices are an LCG per lane, and each round's index depends on
 // the data of the round before (a dependent chain per lane, as in a traversal).
 //
@@ -33,6 +35,12 @@ template <int MODE>
 __global__ void __launch_bounds__(256, 6) k_gather(const uint4* __restrict__ table, uint32_t nrec, int rounds, uint32_t* out)
 {
     const int lane = threadIdx.x & 63;
+    __shared__ uint4 ldsTop[MODE == 7 ? 85 * 4 : 1];
+    if(MODE == 7)
+    {
+        for(uint32_t k = threadIdx.x; k < 85u * 4u; k += 256u) ldsTop[k] = table[k];
+        __syncthreads();
+    }
     uint32_t  s    = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
     uint32_t  acc  = 0;
     for(int r = 0; r < rounds; ++r)
@@ -67,6 +75,23 @@ __global__ void __launch_bounds__(256, 6) k_gather(const uint4* __restrict__ tab
             const uint4* p = table + (size_t)idx * 5;
             const uint4  a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
             acc += a.x ^ b.y ^ c.z ^ d.w ^ e.x;
+        }
+        else if(MODE == 6 || MODE == 7)
+        {
+            const bool     top = (lane & 7) < 3;
+            const uint32_t it  = idx % 85u;
+            if(MODE == 7 && top)
+            {
+                const uint4* p = ldsTop + it * 4;
+                const uint4  a = p[0], b = p[1], c = p[2], d = p[3];
+                acc += a.x ^ b.y ^ c.z ^ d.w;
+            }
+            else
+            {
+                const uint4* p = table + (size_t)(top ? it : idx) * 4;
+                const uint4  a = p[0], b = p[1], c = p[2], d = p[3];
+                acc += a.x ^ b.y ^ c.z ^ d.w;
+            }
         }
         else if(MODE == 5)
         {
@@ -146,5 +171,7 @@ int main(int argc, char** argv)
     run<3>("D  lane: 5 x 16 B of its own 80-B record", table, tableBytes, 80, 5, out, blocks);
     run<4>("E  oct: 8 records of 128 B, 16 B per lane", table, tableBytes, 128, 8, out, blocks);
     run<5>("F  lane: 8 x 16 B of its own 128-B record", table, tableBytes, 128, 8, out, blocks);
+    run<6>("G  like A, 3 lanes in 8 in the first 85 records", table, tableBytes, 64, 4, out, blocks);
+    run<7>("H  like G, those lanes from an LDS copy", table, tableBytes, 64, 4, out, blocks);
     return 0;
 }
