@@ -3,7 +3,7 @@
 set -u
 export TMPDIR=/tmp
 OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out
-ARGS="bench.py --steps 64 --warmup 32 --no-cpu-baseline --pipes 1"
+ARGS="bench.py --steps 64 --warmup 64 --no-cpu-baseline --pipes 1"
 cd ${GRAFT_REPO_ROOT:-$PWD}
 echo "== kernel trace"; timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $OUT/prof_trace -o trace -- python3 $ARGS > $OUT/prof_trace.json 2> $OUT/prof_trace.log || exit 1
 echo "== pmc FETCH_SIZE"; timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_fetch -o fetch -- python3 $ARGS > /dev/null 2> $OUT/prof_fetch.log || exit 1

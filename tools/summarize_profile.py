@@ -11,7 +11,7 @@ def short(n):
     n = n.replace("void ", "")
     return n.split("(")[0]
 
-out = [f"# rocprofv3 summary ({tag}) — `python3 bench.py --steps 32 --warmup 16 --no-cpu-baseline --pipes 1` on one MI355X (one pass in flight, so that a kernel's trace duration is its own; every path-tracing launch covers 16 iterations = 33.2 M pixels)\n"]
+out = [f"# rocprofv3 summary ({tag}) — `python3 bench.py --steps 64 --warmup 64 --no-cpu-baseline --pipes 1` on one MI355X (one pass in flight, so that a kernel's trace duration is its own; a path-tracing launch covers up to 64 iterations = 132.7 M pixels)\n"]
 db = sqlite3.connect(os.path.join(G, "prof_trace", "trace_results.db"))
 out.append("## `rocprofv3 --kernel-trace --stats` (top kernels; durations in microseconds)\n")
 out.append("| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|")
@@ -58,8 +58,13 @@ out.append("FETCH_SIZE / WRITE_SIZE are reported in KiB. Per MI355X_MICROARCH.md
            "reads of the traversal kernels (40 B per ray). The counters sit at the L2's fabric side, so Infinity-Cache hits are included: "
            "traffic leaving L2, an upper bound on HBM traffic.\n")
 out.append("| kernel | launches | FETCH_SIZE KiB/launch (raw) | read MB/launch (x2) | WRITE_SIZE KiB/launch | L2 hit rate | VALU busy (SQ_ACTIVE_INST_VALU*4/SQ_BUSY_CYCLES... see below) |\n|---|---:|---:|---:|---:|---:|---:|")
-for k in ["prt::k_shadow_extend<false>", "prt::k_extend<false>", "prt::k_shadow<false>", "prt::k_shade", "prt::k_generate", "prt::k_resolve"]:
-    if k not in fetch: continue
+def find(prefix):
+    """the non-instrumented single-level instantiation of a kernel, whatever its template argument list looks like"""
+    c = [k for k in fetch if k == prefix or (k.startswith(prefix + "<false") and "true" not in k)]
+    return c[0] if c else None
+WANT = [find(p) for p in ("prt::k_shadow_extend", "prt::k_extend", "prt::k_shadow", "prt::k_shade", "prt::k_generate", "prt::k_resolve")]
+for k in WANT:
+    if k is None or k not in fetch: continue
     f = fetch[k]["FETCH_SIZE"] / nf[k]; w = write[k]["WRITE_SIZE"] / nw[k]
     h = tcc[k].get("TCC_HIT_sum", 0.0); m = tcc[k].get("TCC_MISS_sum", 0.0)
     s = sq[k]
@@ -87,7 +92,7 @@ for k in ["prt::k_shadow_extend<false>", "prt::k_extend<false>", "prt::k_shadow<
     traffic[k.replace("prt::", "").split("<")[0]] = e
 out.append("\nLast column = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (fraction of resident-wave cycles in which the wave is issuing VALU work).\n")
 out.append("### raw SQ counters (sum over launches)\n")
-for k in ["prt::k_shadow_extend<false>", "prt::k_extend<false>", "prt::k_shadow<false>", "prt::k_shade"]:
+for k in WANT[:4]:
     if k in sq: out.append(f"* `{k}`: " + ", ".join(f"{c}={v:.4g}" for c, v in sorted(sq[k].items())))
 open(os.path.join(P, f"{tag}_rocprof_summary.md"), "w").write("\n".join(out) + "\n")
 bj = os.path.join(G, "prof_trace.json")
