@@ -144,7 +144,8 @@ def main():
     ctx.set_flags(capi.FLAG_RUSSIAN_ROULETTE if args.rr else 0)  # additive accumulation: required for the multi-GPU sum
     if args.pipes:
         ctx.set_pipeline_depth(args.pipes)
-    in_flight = ctx.pipeline_depth()
+    # passes of 24 M pixels or more run one after the other on one stream (prt_render); smaller ones rotate over the pipes
+    in_flight = 1 if W * H * min(K, ctx.iteration_batch()) >= (24 << 20) else ctx.pipeline_depth()
     # sample sharding: K iterations per GPU (weak scaling) = iterations 1 .. K*N dealt round-robin
     it_first, it_n, it_stride = sharding.iteration_shard(rank, n_gpus, K * n_gpus)
     assert (it_first, it_n, it_stride) == (1 + rank, K, n_gpus)
@@ -290,8 +291,8 @@ def main():
         binding["lane_utilisation"] = ({"closest": lanes(prof2.closest_steps), "any": lanes(prof2.any_steps)}
                                        if st2 is None else lanes(st2))
         binding["what"] = ("not HBM: the kernel is bound by the latency of dependent, divergent 16-byte gathers (one L2 / "
-                           "Infinity-Cache round trip per node visit, the wave waits for its slowest lane) at the 6 waves per "
-                           "SIMD its registers allow; DESIGN.md section 5")
+                           "Infinity-Cache round trip per node visit below the part of the tree that is staged in LDS, the wave "
+                           "waits for its slowest lane) at the 6 waves per SIMD its registers allow; DESIGN.md section 5")
         achieved = traffic / (ms1 * 1e-3) / 1e9 if traffic and ms1 > 0 else None
         roofline = {"bound": "hbm", "kernel": kname,
                     "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
