@@ -88,7 +88,7 @@ struct Tree
     QuantGrid  grid{};
     float      sceneAbs = 0.0f;
     float      bmin[3] = {0.0f, 0.0f, 0.0f}, bmax[3] = {0.0f, 0.0f, 0.0f};
-    uint32_t   nodeBase = 0, slotBase = 0;  // position in the node / leaf arrays shared by all structures
+    NodePlace  place{0, 0, 0, 0};  // position in the node / leaf arrays shared by all structures (prt_bvh.hpp)
     int32_t    root = 0;
     uint32_t*  dWideIdx = nullptr;  // between tree_layout and tree_emit: BVH4 index of every build node
 };
@@ -131,6 +131,7 @@ struct prt_context
     float4*   dShadeInst = nullptr;  // shading records, caller's order (prt_kernels.hpp ShadeInst)
     uint32_t* dInstBase  = nullptr;  // flattened primitive id of every instance's first triangle, + total
     float     padScale   = 1.0f;
+    uint32_t  nHot       = 0;  // nodes 0 .. nHot-1 of dNodes are the tops of the trees (BvhView::nTop)
     bool      twoLevel() const { return !instances.empty(); }
     uint32_t  gridTwo[6] = {0, 0, 0, 0, 0, 0};  // resident grids of the two-level kernel variants
 
@@ -693,11 +694,12 @@ static void tree_emit(prt_context* c, Tree& t, bool triangles)
 {
     hipStream_t st = c->stream;
     hipLaunchKernelGGL(k_emit_wide, dim3(cdiv(t.nNodes, 256)), dim3(256), 0, st, t.dBuildNodes, t.nNodes, t.lt,
-                       t.dWideIdx, t.grid, c->dNodes, t.nodeBase, t.slotBase);
+                       t.dWideIdx, t.grid, c->dNodes, t.place);
     if(triangles)
         hipLaunchKernelGGL(k_emit_leaves, dim3(cdiv(t.nNodes, 256)), dim3(256), 0, st, t.dBuildNodes, t.nNodes,
-                           c->dVerts, c->dIdx + (size_t)3 * t.first, t.dOrder, c->dTris, t.slotBase);
-    t.root = t.nInner ? (int32_t)t.nodeBase : (int32_t) ~((t.slotBase << 3) | t.N);
+                           c->dVerts, c->dIdx + (size_t)3 * t.first, t.dOrder, c->dTris, t.place.slotBase);
+    // wide node 0 is the root: first of the hot part when the tree has one, else first of the cold part
+    t.root = t.nInner ? (int32_t)(t.place.hotCount ? t.place.hotBase : t.place.coldBase) : (int32_t) ~((t.place.slotBase << 3) | t.N);
 }
 
 static bool is_identity(const float* m)
@@ -844,7 +846,8 @@ static int accel_emit(prt_context* c)
     {
         if((rc = tree_layout(c, c->top))) return rc;
         if(c->top.nInner >= (1u << 26)) return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^26 BVH4 nodes");
-        c->top.nodeBase = c->top.slotBase = 0;
+        c->top.place = NodePlace{0, 0, 0, 0};
+        c->nHot      = c->top.nInner < PRT_TOP_NODES ? c->top.nInner : PRT_TOP_NODES;
         dfree(c->dNodes);
         dfree(c->dTris);
         TCHK(dalloc(c->dNodes, (size_t)(c->top.nInner ? c->top.nInner : 1) * 4));
@@ -857,15 +860,30 @@ static int accel_emit(prt_context* c)
             if((rc = tree_layout(c, t))) return rc;
         if((rc = tlas_build(c))) return rc;
         if((rc = tree_layout(c, c->top))) return rc;
-        uint64_t nb = c->top.nInner, sb = 0;
-        c->top.nodeBase = c->top.slotBase = 0;
+        // hot parts first (LDS-staged by the traversal kernels): a third of the budget for the top level, the rest
+        // shared by the bottom-level structures when they are few enough to get at least 4 nodes each
+        const uint32_t budget = PRT_TOP_NODES;
+        const uint32_t kTop   = c->top.nInner < budget / 3 ? c->top.nInner : budget / 3;
+        const uint32_t kBlas  = c->blas.size() * 4 <= budget - kTop ? (uint32_t)((budget - kTop) / c->blas.size()) : 0u;
+        uint64_t       hot = 0, sb = 0;
+        c->top.place = NodePlace{0, kTop, 0, 0};
+        hot += kTop;
         for(Tree& t : c->blas)
         {
-            t.nodeBase = (uint32_t)nb;
-            t.slotBase = (uint32_t)sb;
-            nb += t.nInner;
+            const uint32_t k = t.nInner < kBlas ? t.nInner : kBlas;
+            t.place          = NodePlace{(uint32_t)hot, k, 0, (uint32_t)sb};
+            hot += k;
             sb += t.N;
         }
+        uint64_t nb = hot;
+        c->top.place.coldBase = (uint32_t)nb;
+        nb += c->top.nInner - c->top.place.hotCount;
+        for(Tree& t : c->blas)
+        {
+            t.place.coldBase = (uint32_t)nb;
+            nb += t.nInner - t.place.hotCount;
+        }
+        c->nHot = (uint32_t)hot;
         if(nb >= (1u << 26) || sb >= (1u << 28)) return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^26 BVH4 nodes");
         dfree(c->dNodes);
         dfree(c->dTris);
@@ -1159,7 +1177,7 @@ static void fill_bvh_view(const prt_context* c, BvhView& b)
     b.inst     = c->dInst;
     b.padScale = c->padScale;
     {
-        uint64_t inner = c->top.nInner;  // the node array starts with the top(-level) tree's nodes, level by level
+        uint64_t inner = c->nHot;  // the node array starts with the tops of the trees (accel_emit)
         static const uint32_t topMax = [] {
             uint32_t v = PRT_TOP_NODES;
             if(const char* e = getenv("PRT_TOP")) v = (uint32_t)atoi(e) < v ? (uint32_t)atoi(e) : v;  // measurement only

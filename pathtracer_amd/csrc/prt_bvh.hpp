@@ -647,11 +647,18 @@ PRT_DEV uint32_t quant_ceil(float v, float qmin, float scale)
     while(q < 65535.0 && (double)qmin + q * (double)scale < (double)v) q += 1.0;
     return (uint32_t)q;
 }
-// nodeBase / slotBase: position of this structure in the node / leaf arrays that the structures of a two-level scene
-// share (0 for a single-level scene); child references are absolute
+// Position of this structure in the node / leaf arrays that the structures of a two-level scene share (single-level:
+// all zero); child references are absolute. The first hotCount nodes of the tree (its top levels: nodes are numbered
+// level by level) go to hotBase.., the others to coldBase..: the hot parts of all structures form the front of the node
+// array, which the traversal kernels stage in LDS (BvhView::nTop).
+struct NodePlace
+{
+    uint32_t hotBase, hotCount, coldBase, slotBase;
+};
+PRT_DEV uint32_t node_place(const NodePlace& p, uint32_t w) { return w < p.hotCount ? p.hotBase + w : p.coldBase + (w - p.hotCount); }
 __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__ nodes, uint32_t nnodes,
                                                    LevelTable lt, const uint32_t* __restrict__ wideIdx, QuantGrid g,
-                                                   uint4* __restrict__ out, uint32_t nodeBase, uint32_t slotBase)
+                                                   uint4* __restrict__ out, NodePlace pl)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= nnodes || nodes[i].count != 0 || (level_of(lt, i) & 1u) != 0u) return;
@@ -679,7 +686,7 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
                 qmn[k][j] = quant_floor(fdec(c.bmin[k]), g.qmin[k], g.qscale[k]);
                 qmx[k][j] = quant_ceil(fdec(c.bmax[k]), g.qmin[k], g.qscale[k]);
             }
-            ref[j] = c.count == 0 ? (int32_t)(wideIdx[slot[j]] + nodeBase) : (int32_t)~(((c.first + slotBase) << 3) | c.count);
+            ref[j] = c.count == 0 ? (int32_t)node_place(pl, wideIdx[slot[j]]) : (int32_t)~(((c.first + pl.slotBase) << 3) | c.count);
         }
         else
         {
@@ -692,7 +699,7 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
             ref[j] = -1;
         }
     }
-    uint4* o = out + (size_t)(wideIdx[i] + nodeBase) * 4;
+    uint4* o = out + (size_t)node_place(pl, wideIdx[i]) * 4;
     for(int k = 0; k < 3; ++k)
         o[k] = make_uint4(qmn[k][0] | (qmn[k][1] << 16), qmn[k][2] | (qmn[k][3] << 16), qmx[k][0] | (qmx[k][1] << 16),
                           qmx[k][2] | (qmx[k][3] << 16));
