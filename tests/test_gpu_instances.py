@@ -224,3 +224,37 @@ def test_instance_errors():
     ctx.build_accel()
     assert ctx.read_bvh()[0].shape[0] > 0
     ctx.close()
+
+
+def test_two_level_context_returns_device_memory():
+    """prt_destroy / a rebuild / a return to the single-level scene give back what a two-level scene allocated (trees,
+    instance tables): free device memory stays put over create-build-update-render-destroy rounds."""
+    import torch
+
+    sc = scenes.instanced_scene(seed=24, n_instances=50, wild=True)
+    W, H = 128, 96
+
+    def round_trip(k):
+        ctx = capi.Context(W, H)
+        ctx.set_scene(sc)
+        ctx.set_instances(sc["blas"], sc["instances"])
+        ctx.build_accel()
+        ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=2))
+        ctx.render(capi.MODE_PATH, 1, 3)
+        ctx.update_instance_transforms(sc["instances"]["transform"])
+        ctx.build_accel()  # rebuild over the existing structures
+        if k % 2:
+            ctx.set_instances(sc["blas"][:0], sc["instances"][:0])
+            ctx.build_accel()
+        ctx.render(capi.MODE_PATH, 1, 2)
+        ctx.close()
+
+    for k in range(4):
+        round_trip(k)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(4, 12):
+        round_trip(k)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (8 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB over eight contexts"
