@@ -1,7 +1,8 @@
 // prt_bvh.hpp — binned-SAH BVH build on the GPU: replaces the BLAS/TLAS construction that the
 // reference hands to vkCmdBuildAccelerationStructureNV (src/vkRTX_setup.cpp:84-132,138-186,391-415;
-// external/NVIDIA_RTX/vkRT_BLAS.cpp:271). One instance, identity transform, opaque, two-sided:
-// a single-level BVH over the triangles of model 0.
+// external/NVIDIA_RTX/vkRT_BLAS.cpp:271, vkRT_TLAS.cpp:262). Opaque, two-sided triangles. The reference's scene — one
+// identity instance of model 0 — is a single tree over the scene's triangles; with prt_set_instances the same builder
+// makes one tree per bottom-level range and one over the instances' world boxes (`given`, leaf size 1).
 //
 // Algorithm: breadth-first, one pass of kernels per tree level, 16 bins per axis, leaves <= PRT_LEAF_MAX (2)
 // triangles. Everything that decides the tree is order-independent: bin counts are integer

@@ -18,9 +18,10 @@
 // Passes (iterations) are independent until `resolve`, so several of them are in flight on separate
 // HIP streams (prt_api.hip); `resolve` runs in iteration order, which keeps the fp32 sums bit-exact.
 //
-// All per-path state is pixel-indexed SoA (float4 records -> 16-byte coalesced accesses); queues
-// hold pixel ids. Queue lengths live in device memory, kernels are persistent (wave-granular work
-// fetch), so the launch sequence is identical every iteration.
+// Per-path state lives at QUEUE SLOTS (FrameView::gen: SoA float4 records, two generations; k_shade writes the
+// survivors of a vertex compacted into the next generation), only the radiance terms are stored by pixel. Queue
+// lengths live in device memory, kernels are persistent (wave-granular work fetch), so the launch sequence is
+// identical every iteration.
 #pragma once
 #include "prt_trace.hpp"
 
