@@ -129,7 +129,8 @@ struct prt_context
     std::vector<prt_instance>   instances;
     float4*   dInst      = nullptr;  // traversal records, top-level leaf order (prt_trace.hpp InstanceRec)
     float4*   dShadeInst = nullptr;  // shading records, caller's order (prt_kernels.hpp ShadeInst)
-    uint32_t* dInstBase  = nullptr;  // flattened primitive id of every instance's first triangle, + total
+    uint32_t* dInstBase  = nullptr;  // flattened primitive id of every instance's first triangle, + total; then the bucket table
+    uint32_t  instShift  = 0;        // bucket of a flattened primitive id = id >> instShift (instance_tables)
     float     padScale   = 1.0f;
     uint32_t  nHot       = 0;  // nodes 0 .. nHot-1 of dNodes are the tops of the trees (BvhView::nTop)
     bool      twoLevel() const { return !instances.empty(); }
@@ -824,15 +825,29 @@ static int instance_tables(prt_context* c)
         q[6] = make_float4(bits(t.first), bits(id ? 1u : 0u), 0.0f, 0.0f);
         q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
+    // Which instance a flattened primitive id belongs to (k_shade): bucket table over the id range, about two buckets per
+    // instance; entry k = the instance that holds id k << instShift, so the search for an id runs over
+    // [table[id >> shift], table[(id >> shift) + 1]] — mostly one or two candidates instead of log2(n) steps.
+    uint32_t shift = 0;
+    while(((b >> shift) + 1) > 2 * (uint64_t)n + 2) ++shift;
+    const size_t nb = (size_t)(b >> shift) + 2;
+    base.resize(n + 1 + nb);
+    for(size_t k = 0, i = 0; k < nb; ++k)
+    {
+        const uint64_t id = (uint64_t)k << shift;
+        while(i + 1 < n && base[i + 1] <= id) ++i;
+        base[n + 1 + k] = (uint32_t)i;
+    }
+    c->instShift = shift;
     dfree(c->dInst);
     dfree(c->dShadeInst);
     dfree(c->dInstBase);
     HIPCHK(c, dalloc(c->dInst, trav.size()));
     HIPCHK(c, dalloc(c->dShadeInst, shade.size()));
-    HIPCHK(c, dalloc(c->dInstBase, n + 1));
+    HIPCHK(c, dalloc(c->dInstBase, base.size()));
     HIPCHK(c, hipMemcpy(c->dInst, trav.data(), trav.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->dShadeInst, shade.data(), shade.size() * sizeof(float4), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->dInstBase, base.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dInstBase, base.data(), base.size() * 4, hipMemcpyHostToDevice));
     return PRT_OK;
 }
 
@@ -1203,6 +1218,8 @@ static void make_views(prt_context* c, const Pipe& p, SceneView& sc, FrameView& 
     sc.ntri         = c->ntri;
     sc.shadeInst    = c->dShadeInst;
     sc.instBase     = c->dInstBase;
+    sc.instLookup   = c->dInstBase ? c->dInstBase + c->instances.size() + 1 : nullptr;
+    sc.instShift    = c->instShift;
     sc.ninst        = (uint32_t)c->instances.size();
     fill_bvh_view(c, sc.bvh);
     f.w       = c->w;

@@ -45,6 +45,8 @@ struct SceneView
     // two-level scenes (kernels instantiated with TWO): instances in the caller's order
     const float4*       shadeInst;  // 8 x float4 per instance (ShadeInst below)
     const uint32_t*     instBase;   // flattened primitive id of every instance's first triangle (ninst + 1 entries)
+    const uint32_t*     instLookup; // instance that holds primitive id k << instShift (prt_api.hip: instance_tables)
+    uint32_t            instShift;
     uint32_t            ninst;
 };
 
@@ -367,7 +369,8 @@ PRT_DEV TriU load_tri(const float4* __restrict__ stri, uint32_t prim)
     t.mat = __float_as_int(q6.x);
     return t;
 }
-// Two-level scenes: the flattened primitive `prim` belongs to the last instance whose base is <= prim; its triangle
+// Two-level scenes: the flattened primitive `prim` belongs to the last instance whose base is <= prim (found through
+// the bucket table: the search runs over the instances that share the id's bucket); its triangle
 // record (object space) is taken to world space the way an instanced scene is flattened (host/Scene.cpp, oracle.cpp
 // shadingVertex): p = (M0*x + M1*y) + (M2*z + M3), n = normalize(N*n) with N = transpose(inverse(M)), a zero normal
 // stays zero, an identity instance is taken bit for bit.
@@ -386,7 +389,8 @@ PRT_DEV VertexU xform_corner(VertexU v, float4 m0, float4 m1, float4 m2, float4 
 }
 PRT_DEV TriU load_tri_inst(const SceneView& sc, uint32_t prim)
 {
-    uint32_t lo = 0, hi = sc.ninst;
+    const uint32_t bucket = prim >> sc.instShift;
+    uint32_t       lo = sc.instLookup[bucket], hi = sc.instLookup[bucket + 1u] + 1u;
     while(hi - lo > 1u)
     {
         const uint32_t mid = (lo + hi) >> 1;
