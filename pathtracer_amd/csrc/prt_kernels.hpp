@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256) k_generate(SceneView sc, FrameView f, con
     }
     st_nt(f.gen[0].rayO + px, make_float4(Ro.x, Ro.y, Ro.z, 0.000001f));
     st_nt(f.gen[0].rayD + px, make_float4(Rd.x, Rd.y, Rd.z, 1.0f));
-    st_nt(f.gen[0].thr + px, make_float4(1.0f, 1.0f, 1.0f, 1.0f));
+    // throughput (1,1,1) and p = 1 of a primary ray are not stored: k_shade(0) knows them
 }
 
 // AO.rgen:185-205 — pixel-centre primary ray, tmin 1e-5
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256, TWO ? PRT_SHADE_WAVES_TWO : PRT_SHADE_WAV
             st.px   = bounce ? ld_nt(gin.px + i) : i;
             st.hit  = ld_nt(gin.hit + i);
             st.rayD = ld_nt(gin.rayD + i);
-            st.thr  = ld_nt(gin.thr + i);
+            st.thr  = bounce ? ld_nt(gin.thr + i) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // primary rays: k_generate
             st.dead = (bounce == 0) && f.dead[i];  // bounce 0: slot == pixel
         }
         return st;
