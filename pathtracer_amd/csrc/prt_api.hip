@@ -1262,15 +1262,23 @@ static void launch_extend(prt_context* c, hipStream_t st, const SceneView& sc, c
                            trace_tune());
 }
 
+static int pipe_ensure(prt_context* c, Pipe& p, size_t npass, int B);
 // AO.rgen: generate -> extend -> AO rays + accumulate, on the context's main stream with pipe 0's buffers.
-static int render_ao(prt_context* c)
+// nsub > 1: that many iterations side by side in one pass (prt_render; not with the literal image semantics): every
+// iteration's term is stored by pass pixel and k_resolve adds them to the image in iteration order.
+static int render_ao(prt_context* c, uint32_t nsub = 1)
 {
     Pipe&       p  = c->pipes[0];
     hipStream_t st = c->stream;
+    if(nsub > 1)
+    {
+        const int rc = pipe_ensure(c, p, (size_t)c->npix * nsub, 0);
+        if(rc) return rc;
+    }
     SceneView   sc;
     FrameView   f;
-    make_views(c, p, sc, f);
-    const uint32_t gridPix = cdiv(c->npix, 256);
+    make_views(c, p, sc, f, nsub, 1);
+    const uint32_t gridPix = cdiv((size_t)c->npix * nsub, 256);
     HIPCHK(c, hipMemsetAsync(p.counters, 0, kCounterWords * 4, st));
     {
         ProfScope ps(c, PRT_K_GENERATE, st);
@@ -1280,15 +1288,29 @@ static int render_ao(prt_context* c)
     {
         ProfScope ps(c, PRT_K_AO_SHADE, st);
         if(c->twoLevel())
-            hipLaunchKernelGGL(k_ao_shade<true>, dim3(c->gridTwo[3]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo, c->flags,
+        {
+            if(nsub > 1)
+                hipLaunchKernelGGL((k_ao_shade<true, true>), dim3(c->gridTwo[3]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo,
+                                   c->flags, p.counters + 1);
+            else
+                hipLaunchKernelGGL((k_ao_shade<true, false>), dim3(c->gridTwo[3]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo,
+                                   c->flags, p.counters + 1);
+        }
+        else if(nsub > 1)
+            hipLaunchKernelGGL((k_ao_shade<false, true>), dim3(c->gridAo), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo, c->flags,
                                p.counters + 1);
         else
-            hipLaunchKernelGGL(k_ao_shade<false>, dim3(c->gridAo), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo, c->flags,
-                               p.counters + 1);
+            hipLaunchKernelGGL((k_ao_shade<false, false>), dim3(c->gridAo), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo,
+                               c->flags, p.counters + 1);
+    }
+    if(nsub > 1)
+    {
+        ProfScope ps(c, PRT_K_RESOLVE, st);
+        hipLaunchKernelGGL(k_resolve, dim3(cdiv(c->npix, 256)), dim3(256), 0, st, c->accum, p.contrib, p.nvert, c->npix, nsub);
     }
     HIPCHK(c, hipGetLastError());
     c->lastPipe = 0;
-    p.lastSub   = 1;  // prt_read_hit_ids: the AO pass wrote the ids of its one iteration at offset 0
+    p.lastSub   = nsub;  // prt_read_hit_ids: the ids of the pass's last iteration
     return PRT_OK;
 }
 
@@ -1463,8 +1485,9 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
     // Several iterations per pass: a launch over B*W*H "pixels" has the same fixed tail as one over W*H, so small
     // frames batch consecutive iterations (pixel k of the pass = image pixel k % (W*H) of iteration
     // first + (k / (W*H)) * stride); k_resolve adds them in iteration order, so the image is bit-identical.
-    const bool batchable = mode == PRT_MODE_PATH && c->batch > 1 && c->ubo.numAArays == 1 &&
-                           !(c->flags & PRT_FLAG_LITERAL) && c->haveAccel && !c->accelStale;
+    const bool batchable = (mode == PRT_MODE_PATH || mode == PRT_MODE_AO) && c->batch > 1 &&
+                           (mode == PRT_MODE_AO || c->ubo.numAArays == 1) && !(c->flags & PRT_FLAG_LITERAL) && c->haveAccel &&
+                           !c->accelStale;
     uint32_t k = 0;
     if(batchable)
     {
@@ -1480,6 +1503,14 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
             if((uint64_t)c->npix * nsub >= (1ull << 31)) nsub = (uint32_t)(((1ull << 31) - 1) / c->npix);  // 32-bit pixel ids
             if(nsub < 2) break;
             c->ubo.iteration    = first + k * stride;
+            if(mode == PRT_MODE_AO)  // (AO.rgen takes nothing from the iteration number: the iterations of a pass are alike)
+            {
+                const int rc = render_ao(c, nsub);
+                if(rc) return rc;
+                c->iterations += nsub;
+                k += nsub;
+                continue;
+            }
             // A large pass fills the GPU by itself: passes in flight on other streams add nothing then (measured at
             // 1080p, 32 / 64 iterations per pass: 8170 / 8280 Mrays/s on one pipe, 8120 / 8250 on three), so such
             // passes all run on pipe 0 and only that pipe's buffers grow to the pass size.

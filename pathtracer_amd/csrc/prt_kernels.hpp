@@ -273,9 +273,10 @@ __global__ void __launch_bounds__(256) k_ao_generate(FrameView f, const prt_unif
     const prt_uniforms* ubo = &ubo_;
     const uint32_t      px  = blockIdx.x * blockDim.x + threadIdx.x;
     if(px >= f.npix) return;
-    if((flags & PRT_FLAG_LITERAL) && !(ubo->iteration > 1u)) f.accum[px] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if((flags & PRT_FLAG_LITERAL) && !(ubo->iteration > 1u)) f.accum[px] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // one iteration per pass
     f3 Ro, Rd;
-    primary_ray(ubo->projViewInverse, px % f.w, px / f.w, f.w, f.h, 0.5f, 0.5f, Ro, Rd);
+    const uint32_t ip = px % f.npixImg;  // several iterations per pass: pixel px of the pass = image pixel ip of iteration px / npixImg
+    primary_ray(ubo->projViewInverse, ip % f.w, ip / f.w, f.w, f.h, 0.5f, 0.5f, Ro, Rd);
     f.gen[0].rayO[px] = make_float4(Ro.x, Ro.y, Ro.z, 0.00001f);
     f.gen[0].rayD[px] = make_float4(Rd.x, Rd.y, Rd.z, 1.0f);
 }
@@ -888,7 +889,9 @@ __global__ void __launch_bounds__(256) k_resolve(float4* __restrict__ accum, con
 // ---------------------------------------------------------------------------------------------
 // AO — AO.rgen:214-272, after k_ao_generate + k_extend
 // ---------------------------------------------------------------------------------------------
-template <bool TWO = false>
+// BATCH: the pass holds several iterations side by side (prt_render); the iteration's term goes to contrib[px] and
+// k_resolve adds the terms of a pixel to E in iteration order, which is the order E.x + ao is evaluated in below.
+template <bool TWO = false, bool BATCH = false>
 __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, FrameView f, const prt_uniforms ubo_,
                                                               uint32_t flags, uint32_t* workCtr)
 {
@@ -915,17 +918,23 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
         {
             const float4   hq   = f.gen[0].hit[px];
             const uint32_t prim = (uint32_t)__float_as_int(hq.x);
-            const float4   E    = f.accum[px];
+            const uint32_t ip   = BATCH ? px % f.npixImg : px;
+            float4         E    = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if(!BATCH) E = f.accum[px];
+            if(BATCH) f.nvert[px] = 1;  // one term per iteration
             if(prim == 0xffffffffu)
             {
-                f.accum[px] = literal ? make_float4(0.1f, 0.1f, 0.1f, 0.0f)
-                                      : make_float4(E.x + 0.1f, E.y + 0.1f, E.z + 0.1f, E.w + 0.0f);
+                if(BATCH)
+                    st_nt(f.contrib + px, make_float4(0.1f, 0.1f, 0.1f, 0.0f));
+                else
+                    f.accum[px] = literal ? make_float4(0.1f, 0.1f, 0.1f, 0.0f)
+                                          : make_float4(E.x + 0.1f, E.y + 0.1f, E.z + 0.1f, E.w + 0.0f);
             }
             else
             {
-                const uint32_t scr0 = scramble_value(sc.scrTable, f.npix, sc.seed, px, 0);
-                const uint32_t scr1 = scramble_value(sc.scrTable, f.npix, sc.seed, px, 1);
-                uint32_t sobolIndex = scramble_value(sc.scrTable, f.npix, sc.seed, px, 2);
+                const uint32_t scr0 = scramble_value(sc.scrTable, f.npixImg, sc.seed, ip, 0);
+                const uint32_t scr1 = scramble_value(sc.scrTable, f.npixImg, sc.seed, ip, 1);
+                uint32_t sobolIndex = scramble_value(sc.scrTable, f.npixImg, sc.seed, ip, 2);
                 const TriU     tri = TWO ? load_tri_inst(sc, prim) : load_tri(sc.stri, prim);
                 const VertexU &v0 = tri.v0, &v1 = tri.v1, &v2 = tri.v2;
                 const f3      bary = mk3(1.0f - hq.y - hq.z, hq.y, hq.z);
@@ -966,7 +975,10 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
                 }
                 nrays += (uint32_t)numAO;
                 const float ao = (float)noHit / (float)numAO;
-                f.accum[px]    = make_float4(E.x + ao, E.y + ao, E.z + ao, E.w + 1.0f);
+                if(BATCH)
+                    st_nt(f.contrib + px, make_float4(ao, ao, ao, 1.0f));
+                else
+                    f.accum[px] = make_float4(E.x + ao, E.y + ao, E.z + ao, E.w + 1.0f);
             }
         }
     }

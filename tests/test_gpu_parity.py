@@ -307,6 +307,62 @@ def test_pipelined_iterations_equal_sequential():
         capi.Context(8, 8).set_pipeline_depth(99)
 
 
+def test_batched_ao_iterations_equal_one_by_one(po):
+    """AO mode batches like path mode (prt_render): several iterations in one pass, their terms added to the image in
+    iteration order. Image, ray count, iteration count and hit ids equal one iteration per pass and the oracle's;
+    a camera that sees past the scene covers the miss term; a path render afterwards still works on the grown buffers;
+    the literal image semantics are not batched."""
+    sc = scenes.random_soup(600, seed=4, extent=3.0, size=0.6)
+    W, H = 160, 96
+    table = np.random.default_rng(5).integers(0, 2**32, (32, H, W), dtype=np.uint64).astype(np.uint32)
+    kw = dict(ao_rays=7, ao_length=0.8)
+    out = []
+    for batch in (1, 2, 5, 64):
+        ctx = capi.Context(W, H)
+        ctx.set_scene(sc)
+        ctx.set_seed(11)
+        ctx.build_accel()
+        ctx.set_iteration_batch(batch)
+        ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, **kw))
+        ctx.render(capi.MODE_AO, 1, 11, 1)
+        ids = ctx.read_hit_ids().tobytes()
+        ctx.upload_scrambles(table)
+        ctx.render(capi.MODE_AO, 12, 3, 2)
+        img_ao = ctx.read_accum().tobytes()
+        ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=2, **kw))
+        ctx.render(capi.MODE_PATH, 1, 3, 1)
+        out.append((img_ao, ctx.read_accum().tobytes(), ctx.stats().rays, ctx.stats().iterations, ids))
+        ctx.close()
+    assert all(o == out[0] for o in out[1:])
+    assert out[0][3] == 17
+    o = po.Oracle(sc, seed=11)
+    o.build_bvh()
+    acc, last, rays = np.zeros((H, W, 4), np.float32), None, 0
+    for it in range(1, 12):
+        acc, last, r = o.render(uniforms.make_uniforms(sc, W, H, iteration=it, **kw), W, H, capi.MODE_AO, accum=acc, want_ids=True)
+        rays += r
+    o.set_scramble_table(table.reshape(32, H * W), W, H)
+    for it in (12, 14, 16):
+        acc, _, r = o.render(uniforms.make_uniforms(sc, W, H, iteration=it, **kw), W, H, capi.MODE_AO, accum=acc, want_ids=True)
+        rays += r
+    assert out[0][0] == acc.tobytes() and out[0][4] == last.tobytes()
+    assert (acc[..., 3] == 0).any() and (acc[..., 3] > 0).any()  # misses and hits
+    # literal semantics: one iteration per pass, whatever the batch says (the image restarts at iteration <= 1)
+    res = []
+    for batch in (1, 8):
+        ctx = capi.Context(W, H)
+        ctx.set_scene(sc)
+        ctx.set_seed(11)
+        ctx.build_accel()
+        ctx.set_flags(capi.FLAG_LITERAL)
+        ctx.set_iteration_batch(batch)
+        ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, **kw))
+        ctx.render(capi.MODE_AO, 0, 5, 1)
+        res.append(ctx.read_accum().tobytes())
+        ctx.close()
+    assert res[0] == res[1]
+
+
 def test_batched_iterations_equal_one_by_one(po):
     """prt_render puts several iterations into one pass over n*W*H pixels (prt_set_iteration_batch): the image,
     the ray count and the hit ids of the last iteration equal those of one iteration per pass — also with a stride
