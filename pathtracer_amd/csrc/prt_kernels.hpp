@@ -897,7 +897,11 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
 {
     const prt_uniforms* ubo = &ubo_;
     __shared__ __align__(16) uint32_t stackLds[PRT_TRACE_LDS_WORDS];
-    const uint4* topLds = stage_top_nodes(sc.bvh, stackLds);
+    // Sobol byte tables of dimensions 0 and 1 (sobol1D_bytes: four reads instead of the 32-step loop, same bits)
+    __shared__ uint32_t sobT[2 * 1024];
+    for(uint32_t k = threadIdx.x; k < 2u * 1024u; k += PRT_TRACE_BLOCK) sobT[k] = sc.sobolBytes[k];
+    const uint4* topLds = stage_top_nodes(sc.bvh, stackLds);  // (its barrier covers sobT as well)
+    __syncthreads();
     const uint32_t      count   = f.npix;
     const int           lane    = threadIdx.x & 63;
     const bool          literal = (flags & PRT_FLAG_LITERAL) != 0;
@@ -948,8 +952,8 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
                 for(int k = 0; k < numAO; ++k)
                 {
                     // hemisphereSample — AO.rgen:153-181
-                    const float s0 = sobol1D(sc.sobol, sobolIndex, 0u, scr0);
-                    const float s1 = sobol1D(sc.sobol, sobolIndex, 1u, scr1);
+                    const float s0 = sobol1D_bytes(sobT, sobolIndex, scr0);
+                    const float s1 = sobol1D_bytes(sobT + 1024, sobolIndex, scr1);
                     sobolIndex++;
                     float       phi, r;
                     const float a = 2.0f * s0 - 1.0f;
