@@ -97,6 +97,17 @@ def test_instanced_batched_render_bit_exact(po):
     for it in range(1, 8):
         acc, _, _ = o.render(uniforms.make_uniforms(sc, W, H, iteration=it, bounces=4), W, H, 0, accum=acc)
     assert g.tobytes() == acc.tobytes()
+    # AO mode batches the same way (k_ao_shade<TWO, BATCH>)
+    ctx.clear_accum()
+    ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, iteration=1, ao_rays=6, ao_length=0.7))
+    ctx.reset_stats()
+    ctx.render(capi.MODE_AO, 1, 5)
+    acc, rays = np.zeros((H, W, 4), np.float32), 0
+    for it in range(1, 6):
+        acc, ids, r = o.render(uniforms.make_uniforms(sc, W, H, iteration=it, ao_rays=6, ao_length=0.7), W, H, 1, accum=acc,
+                               want_ids=True)
+        rays += r
+    assert ctx.read_accum().tobytes() == acc.tobytes() and (ctx.read_hit_ids() == ids).all() and ctx.stats().rays == rays
     ctx.close()
 
 
