@@ -5,6 +5,10 @@ workload, 1920x1080, path tracing, 5 bounces, GGX + area-light NEE.
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+With --gpus N > 1 and no WORLD_SIZE in the environment (no launcher), bench.py starts the N ranks itself (self_launch:
+fresh child processes under torch.distributed.run on 127.0.0.1; the parent makes no GPU call) and relays rank 0's line.
+LOCAL_RANK maps to device `LOCAL_RANK mod visible devices`, so launchers that isolate one device per rank work too.
+
 A "step" is one progressive iteration (1 sample per pixel over the whole image) per GPU. With N > 1 the
 scene is replicated, rank r renders iterations r+1, r+1+N, ... (sample sharding) into its own
 float4 buffer and the buffers are summed with one RCCL all-reduce inside the timed region ("weak" scaling:
@@ -72,6 +76,38 @@ def host_threads():
     return max(1, n)
 
 
+def self_launch(n, argv):
+    """`python3 bench.py --gpus N` without a launcher: start N ranks, one process per GPU, exactly as the driver's
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...` form would. This parent has made
+    no GPU call (torch is not even imported here): the ranks are fresh child processes, nothing is re-executed.
+    Rank 0's JSON line goes to this process's stdout; the exit code is non-zero if any rank failed."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    log(f"[bench] --gpus {n} without WORLD_SIZE: starting {n} ranks on 127.0.0.1:{port}")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:  # relay only rank 0's result line; anything else a rank wrote to stdout goes to stderr
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        log(f"[bench] the {n}-rank run failed (exit code {rc}{', no result line' if line is None else ''})")
+        return rc or 1
+    sys.stdout.write(line)
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,11 +130,15 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: ranks beyond the GPU count share cuda:0")
     ap.add_argument("--dump-accum", default="", help="rank 0 saves the summed accumulation image of the timed region (.npy)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         log(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}")
     n_gpus = world
 
@@ -106,8 +146,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
-    if args.share_gpu and local >= torch.cuda.device_count():
-        local = 0
+    ndev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if ndev < local_world and not args.share_gpu:
+        # fewer visible devices than ranks on this node: either the launcher gave every rank its own device
+        # (HIP_VISIBLE_DEVICES per rank; then ndev == 1 and device 0 is the rank's own), or ranks would share a
+        # GPU, which RCCL refuses and which would not be the measurement asked for
+        if not (ndev == 1 and any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))):
+            raise SystemExit(f"bench.py: {local_world} ranks on this node but {ndev} visible GPU(s); pass --share-gpu "
+                             f"(with --backend gloo) only to rehearse the N > 1 code path on a smaller box")
+    device_index = local % ndev  # one device per rank; isolated ranks see theirs as device 0
+    if rank == 0 and device_index != local:
+        log(f"[bench] LOCAL_RANK {local} -> cuda:{device_index} ({ndev} visible device(s))")
+    local = device_index
     torch.cuda.set_device(local)
     dist = None
     if world > 1:

@@ -136,11 +136,8 @@ def test_group_rccl_plumbing_single_member():
         del os.environ["PRT_GROUP_FORCE_RCCL"]
 
 
-def test_bench_two_ranks_on_one_gpu_equal_a_single_process(tmp_path):
-    """The N > 1 code path of bench.py — one process per rank, pathtracer_amd.sharding's round-robin deal, ONE all-reduce —
-    run as the driver runs it (torch.distributed.run), with two ranks sharing GPU 0 and the gloo backend because the box
-    has one GPU. The summed image equals a single-process render of the same iterations up to fp32 summation order.
-    What this cannot cover: the RCCL transport between two distinct devices (DESIGN.md section 7)."""
+def _bench_two_ranks(tmp_path, launcher, W, H, K, detail, extra=()):
+    import json
     import socket
     import subprocess
     import sys
@@ -148,24 +145,30 @@ def test_bench_two_ranks_on_one_gpu_equal_a_single_process(tmp_path):
     from pathtracer_amd import uniforms
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    W, H, K = 192, 108, 5
     out = tmp_path / "sum.npy"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(K), "--warmup", "1",
-           "--backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-profile", "--width", str(W), "--height", str(H),
-           "--detail", "0.3", "--dump-accum", str(out)]
+    bench_args = ["--gpus", "2", "--share-gpu", "--backend", "gloo", "--steps", str(K), "--warmup", "1", "--no-cpu-baseline",
+                  *extra, "--dump-accum", str(out)]
+    if launcher == "torchrun":
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py")] + bench_args
+    else:  # the form in the driver's BENCH_rNN.cmd: no launcher, bench.py starts its ranks itself
+        cmd = ["python3", "bench.py"] + bench_args
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stderr[-2000:]
-    import json
-    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]  # ONE JSON line, from rank 0
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["parallelism"] == "spp-sharded x2"
+    assert line["steps"] == K and line["config"]["iterations_per_gpu"] == K
     got = np.load(out)
-    sc = scenes.conference_room(seed=2, detail=0.3)
+    sc = scenes.conference_room(seed=2, detail=detail)
     with capi.Context(W, H) as ctx:
         ctx.set_scene(sc)
         ctx.set_seed(2)
@@ -178,3 +181,21 @@ def test_bench_two_ranks_on_one_gpu_equal_a_single_process(tmp_path):
     num = ((got - ref)[..., :3].astype(np.float64) ** 2).mean()
     den = (ref[..., :3].astype(np.float64) ** 2).mean()
     assert num / den < 1e-10
+    return line
+
+
+def test_bench_two_ranks_on_one_gpu_equal_a_single_process(tmp_path):
+    """The N > 1 code path of bench.py — one process per rank, pathtracer_amd.sharding's round-robin deal, ONE all-reduce —
+    run under torch.distributed.run, with two ranks sharing GPU 0 and the gloo backend because the box has one GPU. The
+    summed image equals a single-process render of the same iterations up to fp32 summation order.
+    What this cannot cover: the RCCL transport between two distinct devices (DESIGN.md section 7)."""
+    _bench_two_ranks(tmp_path, "torchrun", 192, 108, 5, 0.3,
+                     ("--no-profile", "--width", "192", "--height", "108", "--detail", "0.3"))
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus 2 ...` with no launcher and no WORLD_SIZE (the command form of the driver's BENCH_rNN.cmd)
+    starts two ranks itself — at the metric's own size: 328 k triangles, 1920x1080, roofline leg included — and prints
+    one line with n_gpus == 2 whose ray count and summed image are those of a single process."""
+    line = _bench_two_ranks(tmp_path, "self", 1920, 1080, 4, 1.4)
+    assert line["roofline"] and line["roofline"]["ms_per_launch"] > 0

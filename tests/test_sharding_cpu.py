@@ -75,3 +75,25 @@ def test_world2_gloo_sum_equals_single_process(po, tmp_path):
     num = ((got - ref)[..., :3] ** 2).mean()
     den = (ref[..., :3] ** 2).mean()
     assert num / den < 1e-10  # fp32 reassociation only
+
+
+def test_bench_self_launch_starts_the_ranks_and_propagates_failure():
+    """`python3 bench.py --gpus 2` with no WORLD_SIZE must start 2 ranks itself (fresh children; the parent never touches
+    the GPU). Without a GPU every rank refuses to run (no CPU fallback), and the parent must report that as a failure
+    instead of printing a line for fewer GPUs than asked."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("the GPU form of this test is tests/test_gpu_group.py::test_bench_starts_its_own_ranks")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode != 0
+    assert "starting 2 ranks" in res.stderr
+    assert res.stderr.count("bench.py needs a GPU") >= 2  # both ranks came up and both said so
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]
