@@ -694,11 +694,13 @@ static int tree_layout(prt_context* c, Tree& t)
 static void tree_emit(prt_context* c, Tree& t, bool triangles)
 {
     hipStream_t st = c->stream;
+    const uint32_t* idx = c->dIdx + (size_t)3 * t.first;
     hipLaunchKernelGGL(k_emit_wide, dim3(cdiv(t.nNodes, 256)), dim3(256), 0, st, t.dBuildNodes, t.nNodes, t.lt,
-                       t.dWideIdx, t.grid, c->dNodes, t.place);
+                       t.dWideIdx, t.grid, c->dNodes, t.place, triangles ? c->dVerts : (const prt_vertex*)nullptr, idx,
+                       t.dOrder);
     if(triangles)
         hipLaunchKernelGGL(k_emit_leaves, dim3(cdiv(t.nNodes, 256)), dim3(256), 0, st, t.dBuildNodes, t.nNodes,
-                           c->dVerts, c->dIdx + (size_t)3 * t.first, t.dOrder, c->dTris, t.place.slotBase);
+                           c->dVerts, idx, t.dOrder, c->dTris, t.place.slotBase, t.nInner ? 1u : 0u);
     // wide node 0 is the root: first of the hot part when the tree has one, else first of the cold part
     t.root = t.nInner ? (int32_t)(t.place.hotCount ? t.place.hotBase : t.place.coldBase) : (int32_t) ~((t.place.slotBase << 3) | t.N);
 }

@@ -657,9 +657,42 @@ struct NodePlace
     uint32_t hotBase, hotCount, coldBase, slotBase;
 };
 PRT_DEV uint32_t node_place(const NodePlace& p, uint32_t w) { return w < p.hotCount ? p.hotBase + w : p.coldBase + (w - p.hotCount); }
+// The code of a leaf reference (prt_trace.hpp, leaf_test): its triangle count, or 3 for two triangles that form a fan
+// (A, B, C), (A, C, D) — same positions bit for bit — and can share one 64-byte slot. `swap`: the leaf's second triangle
+// is the one that comes first in the fan. verts == nullptr (the top level of a two-level scene: leaves are instances) or
+// a tree that is one leaf: plain counts.
+PRT_DEV bool same_pos(const float* a, const float* b)
+{
+    return __float_as_uint(a[0]) == __float_as_uint(b[0]) && __float_as_uint(a[1]) == __float_as_uint(b[1]) &&
+           __float_as_uint(a[2]) == __float_as_uint(b[2]);
+}
+PRT_DEV bool is_fan(const prt_vertex* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t p, uint32_t q)
+{
+    return same_pos(verts[idx[3 * p]].p, verts[idx[3 * q]].p) && same_pos(verts[idx[3 * p + 2]].p, verts[idx[3 * q + 1]].p);
+}
+PRT_DEV uint32_t leaf_code(const prt_vertex* __restrict__ verts, const uint32_t* __restrict__ idx,
+                           const uint32_t* __restrict__ order, uint32_t first, uint32_t count, bool& swap)
+{
+    swap = false;
+#if PRT_LEAF_QUAD
+    if(verts && count == 2u)
+    {
+        const uint32_t p = order[first], q = order[first + 1];
+        if(is_fan(verts, idx, p, q)) return 3u;
+        if(is_fan(verts, idx, q, p))
+        {
+            swap = true;
+            return 3u;
+        }
+    }
+#endif
+    return count;
+}
 __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__ nodes, uint32_t nnodes,
                                                    LevelTable lt, const uint32_t* __restrict__ wideIdx, QuantGrid g,
-                                                   uint4* __restrict__ out, NodePlace pl)
+                                                   uint4* __restrict__ out, NodePlace pl,
+                                                   const prt_vertex* __restrict__ verts, const uint32_t* __restrict__ idx,
+                                                   const uint32_t* __restrict__ order)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= nnodes || nodes[i].count != 0 || (level_of(lt, i) & 1u) != 0u) return;
@@ -687,7 +720,9 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
                 qmn[k][j] = quant_floor(fdec(c.bmin[k]), g.qmin[k], g.qscale[k]);
                 qmx[k][j] = quant_ceil(fdec(c.bmax[k]), g.qmin[k], g.qscale[k]);
             }
-            ref[j] = c.count == 0 ? (int32_t)node_place(pl, wideIdx[slot[j]]) : (int32_t)~(((c.first + pl.slotBase) << 3) | c.count);
+            bool swap;
+            ref[j] = c.count == 0 ? (int32_t)node_place(pl, wideIdx[slot[j]])
+                                  : (int32_t)~(((c.first + pl.slotBase) << 3) | leaf_code(verts, idx, order, c.first, c.count, swap));
         }
         else
         {
@@ -706,23 +741,37 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
                           qmx[k][2] | (qmx[k][3] << 16));
     o[3] = make_uint4((uint32_t)ref[0], (uint32_t)ref[1], (uint32_t)ref[2], (uint32_t)ref[3]);
 }
-// Leaf records. A leaf over order[first .. first+count) keeps its triangles (3 x float4 each, prim id in v0.w) in the
-// 128-byte slots first .. first+count-1 of the triangle array, packed from the start of slot `first`: a leaf of <= 2
-// triangles is ONE aligned 128-byte line. Measured (tools/ubench_gather.hip): what a divergent gather costs a CU is the
-// number of 128-byte lines it touches, and triangle records packed at 48-byte pitch straddle a line boundary in
-// 25 % (one triangle) / 62 % (two) of the leaves. The slots that follow `first` inside a leaf stay unused (never read).
-#define PRT_LEAF_SLOT_F4 8  // float4 per slot
+// Leaf records. A leaf over order[first .. first+count) owns the 64-byte slots first .. first+count-1 of the triangle
+// array and keeps its triangles packed from the start of slot `first`, 3 x float4 each (prim id in v0.w) — or, for a
+// fan (leaf_code 3), its four corners in slot `first` alone: (A | id of the first triangle), (B | id of the second),
+// (C | 0), (D | 0). Measured (tools/ubench_gather.hip): what a divergent gather costs a CU is the number of 64-byte
+// sectors it touches; a single triangle and a fan touch one. `fans` = false for a tree that is one leaf (its reference
+// is made on the host from the count alone).
 __global__ void __launch_bounds__(256) k_emit_leaves(const BuildNode* __restrict__ nodes, uint32_t nnodes,
                                                      const prt_vertex* __restrict__ verts,
                                                      const uint32_t* __restrict__ idx,
                                                      const uint32_t* __restrict__ order, float4* __restrict__ tris,
-                                                     uint32_t slotBase)
+                                                     uint32_t slotBase, uint32_t fans)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= nnodes) return;
     const uint32_t first = nodes[i].first, count = nodes[i].count;
     if(count == 0) return;
     float4* o = tris + (size_t)(first + slotBase) * PRT_LEAF_SLOT_F4;
+    bool    swap = false;
+    if(fans && leaf_code(verts, idx, order, first, count, swap) == 3u)
+    {
+        const uint32_t p = order[first + (swap ? 1u : 0u)], q = order[first + (swap ? 0u : 1u)];
+        const float*   a = verts[idx[3 * p]].p;
+        const float*   b = verts[idx[3 * p + 1]].p;
+        const float*   c = verts[idx[3 * p + 2]].p;
+        const float*   d = verts[idx[3 * q + 2]].p;
+        o[0]             = make_float4(a[0], a[1], a[2], __int_as_float((int)p));
+        o[1]             = make_float4(b[0], b[1], b[2], __int_as_float((int)q));
+        o[2]             = make_float4(c[0], c[1], c[2], 0.0f);
+        o[3]             = make_float4(d[0], d[1], d[2], 0.0f);
+        return;
+    }
     for(uint32_t q = 0; q < count; ++q)
     {
         const uint32_t p = order[first + q];

@@ -41,6 +41,18 @@ namespace prt {
 #ifndef PRT_TRI_PREFETCH
 #define PRT_TRI_PREFETCH 0
 #endif
+#ifndef PRT_NODE_ASM
+#define PRT_NODE_ASM 0
+#endif
+// leaf records: 64-byte slots; two triangles that form a fan share one slot (leaf_test)
+#define PRT_LEAF_SLOT_F4 4
+#ifndef PRT_LEAF_QUAD
+#if defined(PRT_LEAF_MAX) && PRT_LEAF_MAX != 2
+#define PRT_LEAF_QUAD 0  // code 3 means three triangles there
+#else
+#define PRT_LEAF_QUAD 1
+#endif
+#endif
 #define PRT_SPILL_STACK (100 - PRT_LDS_STACK)
 #define PRT_MAX_DEPTH 64  // depth limit of the binary build tree (=> <= 33 BVH4 levels, <= 100 stack entries)
 #ifndef PRT_TRACE_BLOCK
@@ -181,31 +193,36 @@ PRT_DEV void ray_prepare(const BvhView& bvh, f3 o, float tmin, f3 d, float tmax,
 #undef PRT_SLAB_SETUP
 }
 
-PRT_DEV bool tri_test(const RayCtx& r, float sceneAbs, float4 q0, float4 q1, float4 q2, float& tOut, float& uOut,
-                      float& vOut)
+// A vertex relative to the ray origin: the coordinate along the ray's major axis (kz), the two minor ones, and the minor
+// ones after the shear of the watertight test.
+struct TriVtx
 {
-    int kx = r.kz + 1; if(kx == 3) kx = 0;
-    int ky = kx + 1; if(ky == 3) ky = 0;
-    const float Ax_ = q0.x - r.ox, Ay_ = q0.y - r.oy, Az_ = q0.z - r.oz;
-    const float Bx_ = q1.x - r.ox, By_ = q1.y - r.oy, Bz_ = q1.z - r.oz;
-    const float Cx_ = q2.x - r.ox, Cy_ = q2.y - r.oy, Cz_ = q2.z - r.oz;
-    const float Akz = sel3(Ax_, Ay_, Az_, r.kz), Bkz = sel3(Bx_, By_, Bz_, r.kz), Ckz = sel3(Cx_, Cy_, Cz_, r.kz);
-    const float Ax = sel3(Ax_, Ay_, Az_, kx) - r.Sx * Akz;
-    const float Ay = sel3(Ax_, Ay_, Az_, ky) - r.Sy * Akz;
-    const float Bx = sel3(Bx_, By_, Bz_, kx) - r.Sx * Bkz;
-    const float By = sel3(Bx_, By_, Bz_, ky) - r.Sy * Bkz;
-    const float Cx = sel3(Cx_, Cy_, Cz_, kx) - r.Sx * Ckz;
-    const float Cy = sel3(Cx_, Cy_, Cz_, ky) - r.Sy * Ckz;
-    float       U  = Cx * By - Cy * Bx;
-    float       V  = Ax * Cy - Ay * Cx;
-    float       W  = Bx * Ay - By * Ax;
+    float kx, ky, kz;  // (q - o)[kx], [ky], [kz]
+    float x, y;        // sheared: kx - Sx*kz, ky - Sy*kz
+};
+PRT_DEV TriVtx tri_vertex(const RayCtx& r, int kx, int ky, float4 q)
+{
+    const float dx = q.x - r.ox, dy = q.y - r.oy, dz = q.z - r.oz;
+    TriVtx      v;
+    v.kz = sel3(dx, dy, dz, r.kz);
+    v.kx = sel3(dx, dy, dz, kx);
+    v.ky = sel3(dx, dy, dz, ky);
+    v.x  = v.kx - r.Sx * v.kz;
+    v.y  = v.ky - r.Sy * v.kz;
+    return v;
+}
+// The test proper, from the prepared corners and the three edge functions as fp32 evaluates them:
+// U = C.x*B.y - C.y*B.x, V = A.x*C.y - A.y*C.x, W = B.x*A.y - B.y*A.x.
+PRT_DEV bool tri_core(const RayCtx& r, float sceneAbs, const TriVtx& A, const TriVtx& B, const TriVtx& C, float U, float V,
+                      float W, float& tOut, float& uOut, float& vOut)
+{
     if(U == 0.0f || V == 0.0f || W == 0.0f)
     {
-        const double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+        const double CxBy = (double)C.x * (double)B.y, CyBx = (double)C.y * (double)B.x;
         U                 = (float)(CxBy - CyBx);
-        const double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+        const double AxCy = (double)A.x * (double)C.y, AyCx = (double)A.y * (double)C.x;
         V                 = (float)(AxCy - AyCx);
-        const double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+        const double BxAy = (double)B.x * (double)A.y, ByAx = (double)B.y * (double)A.x;
         W                 = (float)(BxAy - ByAx);
     }
     if((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f))
@@ -213,9 +230,9 @@ PRT_DEV bool tri_test(const RayCtx& r, float sceneAbs, float4 q0, float4 q1, flo
     const float det = (U + V) + W;
     if(det == 0.0f)
         return false;
-    const float Az  = r.Sz * Akz;
-    const float Bz  = r.Sz * Bkz;
-    const float Cz  = r.Sz * Ckz;
+    const float Az  = r.Sz * A.kz;
+    const float Bz  = r.Sz * B.kz;
+    const float Cz  = r.Sz * C.kz;
     const float T   = (U * Az + V * Bz) + W * Cz;
     const float rcp = 1.0f / det;
     const float t   = T * rcp;
@@ -233,17 +250,26 @@ PRT_DEV bool tri_test(const RayCtx& r, float sceneAbs, float4 q0, float4 q1, flo
         amax       = gmax(amax, gabs(r.oy));
         amax       = gmax(amax, gabs(r.oz));
         const float hpad = 9.5367431640625e-07f * amax;  // 16 * 2^-24
-        const float zh   = ((U * Akz + V * Bkz) + W * Ckz) * rcp;
+        const float zh   = ((U * A.kz + V * B.kz) + W * C.kz) * rcp;
         const float xh = r.Sx * zh, yh = r.Sy * zh;
-        const float Akx = sel3(Ax_, Ay_, Az_, kx), Bkx = sel3(Bx_, By_, Bz_, kx), Ckx = sel3(Cx_, Cy_, Cz_, kx);
-        if(xh < gmin(gmin(Akx, Bkx), Ckx) - hpad || xh > gmax(gmax(Akx, Bkx), Ckx) + hpad) return false;
-        const float Aky = sel3(Ax_, Ay_, Az_, ky), Bky = sel3(Bx_, By_, Bz_, ky), Cky = sel3(Cx_, Cy_, Cz_, ky);
-        if(yh < gmin(gmin(Aky, Bky), Cky) - hpad || yh > gmax(gmax(Aky, Bky), Cky) + hpad) return false;
+        if(xh < gmin(gmin(A.kx, B.kx), C.kx) - hpad || xh > gmax(gmax(A.kx, B.kx), C.kx) + hpad) return false;
+        if(yh < gmin(gmin(A.ky, B.ky), C.ky) - hpad || yh > gmax(gmax(A.ky, B.ky), C.ky) + hpad) return false;
     }
     tOut = t;
     uOut = V * rcp;
     vOut = W * rcp;
     return true;
+}
+PRT_DEV bool tri_test(const RayCtx& r, float sceneAbs, float4 q0, float4 q1, float4 q2, float& tOut, float& uOut,
+                      float& vOut)
+{
+    int kx = r.kz + 1; if(kx == 3) kx = 0;
+    int ky = kx + 1; if(ky == 3) ky = 0;
+    const TriVtx A = tri_vertex(r, kx, ky, q0), B = tri_vertex(r, kx, ky, q1), C = tri_vertex(r, kx, ky, q2);
+    const float  U = C.x * B.y - C.y * B.x;
+    const float  V = A.x * C.y - A.y * C.x;
+    const float  W = B.x * A.y - B.y * A.x;
+    return tri_core(r, sceneAbs, A, B, C, U, V, W, tOut, uOut, vOut);
 }
 
 // ---- per-lane stack: LDS [entry][thread] + scratch spill --------------------------------------------
@@ -291,6 +317,41 @@ PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_
                         int32_t* spill, const uint4* top)
 {
     uint4 bx, by, bz, cq;
+#if PRT_NODE_ASM
+    {
+        // Lanes below nTop read their node from the LDS copy, the others from memory, into the SAME registers. Written
+        // by the compiler as if / else, the second group's loads wait for the first group's (a write-after-write on the
+        // destination registers as far as its s_waitcnt insertion can tell), so a step pays the memory round trip AND
+        // the LDS round trip. The lanes are disjoint, so there is no hazard: both groups' loads are issued back to back
+        // under their own exec masks and waited for together.
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4              a, b, c, d;
+        unsigned long long sv;
+        const uint32_t     off  = (uint32_t)cur << 6;
+        const uint32_t     loff = off + (uint32_t)(uintptr_t)top;
+        asm volatile("v_cmp_gt_u32_e32 vcc, %[ntop], %[cur]\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "s_andn2_b64 exec, exec, vcc\n\t"
+                     "global_load_dwordx4 %[a], %[off], %[base]\n\t"
+                     "global_load_dwordx4 %[b], %[off], %[base] offset:16\n\t"
+                     "global_load_dwordx4 %[c], %[off], %[base] offset:32\n\t"
+                     "global_load_dwordx4 %[d], %[off], %[base] offset:48\n\t"
+                     "s_and_b64 exec, %[sv], vcc\n\t"
+                     "ds_read_b128 %[a], %[loff]\n\t"
+                     "ds_read_b128 %[b], %[loff] offset:16\n\t"
+                     "ds_read_b128 %[c], %[loff] offset:32\n\t"
+                     "ds_read_b128 %[d], %[loff] offset:48\n\t"
+                     "s_mov_b64 exec, %[sv]\n\t"
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [sv] "=&s"(sv)
+                     : [cur] "v"(cur), [ntop] "s"(bvh.nTop), [off] "v"(off), [base] "s"(bvh.nodes), [loff] "v"(loff)
+                     : "vcc", "memory");
+        bx = make_uint4(a.x, a.y, a.z, a.w);
+        by = make_uint4(b.x, b.y, b.z, b.w);
+        bz = make_uint4(c.x, c.y, c.z, c.w);
+        cq = make_uint4(d.x, d.y, d.z, d.w);
+    }
+#else
     if(PRT_TOP_NODES && (uint32_t)cur < bvh.nTop)
     {
         // an LDS-typed pointer: ds_read_b128, not a flat load that the compiler would merge with the global one below
@@ -308,6 +369,7 @@ PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_
         const uint4* np = (const uint4*)((const char*)bvh.nodes + ((uint32_t)cur << 6));
         bx = np[0]; by = np[1]; bz = np[2]; cq = np[3];
     }
+#endif
     const float  inf = __builtin_inff();
     // words: .x = min of children 0,1  .y = min of 2,3  .z = max of 0,1  .w = max of 2,3 (16 bits each)
     const uint32_t nx01 = r.negx ? bx.z : bx.x, nx23 = r.negx ? bx.w : bx.y;
@@ -369,6 +431,31 @@ PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_
 
 // All triangles of one leaf. Returns true when an ANY ray found an occluder.
 // sceneAbs / primBase: of the structure the lane is in (single-level: bvh.sceneAbs, 0)
+// Leaf reference = ~((slot << 3) | code); a slot is 64 bytes (one sector: what a divergent gather costs is the number of
+// sectors it touches), a leaf over `count` triangles owns `count` consecutive slots. code = count: the triangles follow each
+// other, 3 x float4 each (prim id in v0.w). code 3 (PRT_LEAF_QUAD, leaves of <= 2): two triangles that form a fan
+// (A, B, C), (A, C, D) — the two halves of a quad, 9 leaves in 10 of a tessellated scene — stored as the four corners in ONE
+// slot: rows (A | id0), (B | id1), (C | -), (D | -). Same floats into the same arithmetic as two separate tests: the corners
+// are sheared once each, and the second triangle's third edge function B'.x*A'.y - B'.y*A'.x = C.x*A.y - C.y*A.x is
+// exactly -(A.x*C.y - A.y*C.x), the first one's second (products commute, a - b = -(b - a) in IEEE arithmetic).
+template <bool ANY>
+PRT_DEV bool leaf_hit(Hit& best, float tt, float uu, float vv, uint32_t p)
+{
+    if(ANY)
+    {
+        best.prim = p;
+        best.t    = tt;
+        return true;
+    }
+    if(tt < best.t || (tt == best.t && p < best.prim))
+    {
+        best.t    = tt;
+        best.u    = uu;
+        best.v    = vv;
+        best.prim = p;
+    }
+    return false;
+}
 template <bool ANY, bool INSTR>
 PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit& best, TraceCount& tc, float sceneAbs,
                        uint32_t primBase)
@@ -376,7 +463,52 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
     const uint32_t ref   = ~(uint32_t)leafRef;
     const uint32_t first = ref >> 3, count = ref & 7u;
     if(count == 0) return false;
-    const float4* t = bvh.tris + (size_t)first * 8;  // the leaf's 128-byte slot (k_emit_leaves)
+    const float4* t = bvh.tris + (size_t)first * PRT_LEAF_SLOT_F4;  // the leaf's first 64-byte slot (k_emit_leaves)
+#if PRT_LEAF_QUAD
+    {
+        // count is 1, 2 or 3 (fan). One code path for all three, so that a wave whose lanes hold different kinds of leaf
+        // runs two tests, not three: the first triangle is rows 0-2 in every form; the second one's corners are prepared
+        // per form (the short divergent part), its test is shared.
+        const float4 qa = t[0], qb = t[1], qc = t[2], qd = t[3];
+        int kx = r.kz + 1; if(kx == 3) kx = 0;
+        int ky = kx + 1; if(ky == 3) ky = 0;
+        const TriVtx A = tri_vertex(r, kx, ky, qa), B = tri_vertex(r, kx, ky, qb), C = tri_vertex(r, kx, ky, qc);
+        const float  U0 = C.x * B.y - C.y * B.x;
+        const float  V0 = A.x * C.y - A.y * C.x;
+        const float  W0 = B.x * A.y - B.y * A.x;
+        float        tt, uu, vv;
+        if(INSTR) tc.tris++;
+        if(tri_core(r, sceneAbs, A, B, C, U0, V0, W0, tt, uu, vv))
+            if(leaf_hit<ANY>(best, tt, uu, vv, primBase + (uint32_t)__float_as_int(qa.w))) return true;
+        if(count == 1u) return false;
+        TriVtx   A1, B1, C1;
+        float    W1;
+        uint32_t id1;
+        if(count == 3u)
+        {
+            A1  = A;
+            B1  = C;
+            C1  = tri_vertex(r, kx, ky, qd);
+            W1  = -V0;
+            id1 = (uint32_t)__float_as_int(qb.w);
+        }
+        else
+        {
+            const float4 qe = t[4], qf = t[5];
+            A1  = tri_vertex(r, kx, ky, qd);
+            B1  = tri_vertex(r, kx, ky, qe);
+            C1  = tri_vertex(r, kx, ky, qf);
+            W1  = B1.x * A1.y - B1.y * A1.x;
+            id1 = (uint32_t)__float_as_int(qd.w);
+        }
+        const float U1 = C1.x * B1.y - C1.y * B1.x;
+        const float V1 = A1.x * C1.y - A1.y * C1.x;
+        if(INSTR) tc.tris++;
+        if(tri_core(r, sceneAbs, A1, B1, C1, U1, V1, W1, tt, uu, vv))
+            if(leaf_hit<ANY>(best, tt, uu, vv, primBase + id1)) return true;
+        return false;
+    }
+#else
 #if PRT_TRI_PREFETCH
     float4        a = t[0], b = t[1], c = t[2];
 #endif
@@ -397,22 +529,7 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
         float tt, uu, vv;
         if(INSTR) tc.tris++;
         if(tri_test(r, sceneAbs, a, b, c, tt, uu, vv))
-        {
-            const uint32_t p = primBase + (uint32_t)__float_as_int(a.w);
-            if(ANY)
-            {
-                best.prim = p;
-                best.t    = tt;
-                return true;
-            }
-            if(tt < best.t || (tt == best.t && p < best.prim))
-            {
-                best.t    = tt;
-                best.u    = uu;
-                best.v    = vv;
-                best.prim = p;
-            }
-        }
+            if(leaf_hit<ANY>(best, tt, uu, vv, primBase + (uint32_t)__float_as_int(a.w))) return true;
 #if PRT_TRI_PREFETCH
         a = na;
         b = nb;
@@ -420,6 +537,7 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
 #endif
     }
     return false;
+#endif
 }
 
 PRT_DEV Hit hit_none(float tmax)
@@ -681,7 +799,8 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
             if(INSTR)
             {
                 // the wave runs as many sequential tests as its largest leaf; lTri counts the tests that did work
-                const uint32_t cnt = has ? (~(uint32_t)leaf & 7u) : 0u;
+                uint32_t cnt = has ? (~(uint32_t)leaf & 7u) : 0u;
+                if(PRT_LEAF_QUAD && cnt == 3u) cnt = 2u;
                 uint32_t       tot = cnt, mx = cnt;
                 for(int o = 32; o > 0; o >>= 1)
                 {
