@@ -245,6 +245,7 @@ def main():
         np.save(args.dump_accum, accum.cpu().numpy())
 
     stats = ctx.stats()
+    pass_iters = ctx.pass_iterations() or 1  # what the timed render used (the memory policy may have split the passes)
     rays = torch.tensor([float(stats.rays)], dtype=torch.float64, device=f"cuda:{local}")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
     if dist:
@@ -407,7 +408,7 @@ def main():
                        "iterations_per_gpu": K, "parallelism": f"spp-sharded x{n_gpus}" if n_gpus > 1 else "single GPU",
                        "rays_total": int(total_rays), "rays_per_sample": round(total_rays / (K * n_gpus * W * H), 3),
                        "bvh_build_ms": round(st.bvh_build_ms, 2), "image_finite": finite,
-                       "iterations_in_flight": in_flight, "iterations_per_pass": ctx.iteration_batch(), "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
+                       "iterations_in_flight": in_flight, "iterations_per_pass": pass_iters, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "kernels_standalone": kernels,

@@ -173,6 +173,14 @@ int prt_get_pipeline_depth(const prt_context* ctx); /* current depth (default: 3
  * affected. No counterpart in the reference. */
 int prt_set_iteration_batch(prt_context* ctx, int n);
 int prt_get_iteration_batch(const prt_context* ctx);
+/* Memory policy of prt_render (no counterpart in the reference). A pass of n iterations needs about
+ * (218 + 16 * bounces) bytes per pixel and iteration (38 GB at 1080p, 5 bounces, 64 iterations). When those buffers cannot
+ * be allocated — hipErrorOutOfMemory, or more than `bytes` (0 = no bound; default: environment PRT_MAX_PASS_BYTES) —
+ * prt_render halves the iterations per pass and tries again, down to one iteration per pass, whose buffers exist since
+ * prt_create; the image is the same bit for bit. prt_get_pass_iterations: iterations per pass that the last prt_render
+ * actually used (0: none rendered yet). */
+int prt_set_pass_memory_limit(prt_context* ctx, uint64_t bytes);
+int prt_get_pass_iterations(const prt_context* ctx);
 /* vkQueueWaitIdle — vkTools.cpp:212 */
 int prt_sync(prt_context* ctx);
 

@@ -25,6 +25,7 @@ EXPORTS = [
     "prt_read_hit_ids", "prt_get_stats", "prt_reset_stats", "prt_trace", "prt_trace_device", "prt_trace_device_noalloc", "prt_read_bvh",
     "prt_read_sobol", "prt_set_profiling", "prt_set_profiling_mask", "prt_get_profile", "prt_set_pipeline_depth", "prt_get_pipeline_depth",
     "prt_update_vertices", "prt_refit_accel", "prt_write_accum", "prt_set_iteration_batch", "prt_get_iteration_batch",
+    "prt_set_pass_memory_limit", "prt_get_pass_iterations",
     "prt_group_create", "prt_group_destroy", "prt_group_last_error", "prt_group_size", "prt_group_uses_rccl",
     "prt_group_context", "prt_group_set_scene", "prt_group_set_scramble_seed", "prt_group_set_uniforms",
     "prt_group_set_flags", "prt_group_clear_accum", "prt_group_render", "prt_group_reduce", "prt_group_read_accum",
@@ -107,6 +108,8 @@ def lib():
         L.prt_get_pipeline_depth.argtypes = [vp]
         L.prt_set_iteration_batch.argtypes = [vp, i32]
         L.prt_get_iteration_batch.argtypes = [vp]
+        L.prt_set_pass_memory_limit.argtypes = [vp, C.c_uint64]
+        L.prt_get_pass_iterations.argtypes = [vp]
         L.prt_update_vertices.argtypes = [vp, vp, sz]
         L.prt_refit_accel.argtypes = [vp]
         L.prt_write_accum.argtypes = [vp, vp]
@@ -257,6 +260,14 @@ class Context:
 
     def iteration_batch(self):
         return int(self.L.prt_get_iteration_batch(self.h_))
+
+    def set_pass_memory_limit(self, nbytes):
+        """Upper bound of the per-pass buffers of prt_render (0 = none): larger passes are split (same image)."""
+        self._chk(self.L.prt_set_pass_memory_limit(self.h_, int(nbytes)))
+
+    def pass_iterations(self):
+        """Iterations per pass the last render() actually used (the memory policy may have shrunk the batch)."""
+        return int(self.L.prt_get_pass_iterations(self.h_))
 
     def clear_accum(self):
         self._chk(self.L.prt_clear_accum(self.h_))

@@ -102,6 +102,10 @@ struct prt_context
     int         numCU = 256;
     uint32_t    gridExtend = 0, gridShadow = 0, gridBatch = 0, gridAo = 0, gridFused = 0, gridShade = 0;
     bool        fuse = true;  // shadow(b) + extend(b+1) in one launch (PRT_FUSE=0 turns it off)
+    uint32_t    batchFit = 0;      // iterations per pass that the last attempt could allocate (0 = not yet limited)
+    uint32_t    batchUsed = 0;     // iterations per pass of the last batched pass (prt_get_pass_iterations)
+    uint64_t    passBytesMax = 0;  // memory policy: upper bound of the per-pass buffers (0 = none), PRT_MAX_PASS_BYTES
+    bool        oom = false;       // the last pipe allocation failed for lack of memory
     uint32_t    batch = 1;    // iterations per pass in prt_render (see there)  // resident blocks of the persistent kernels
     std::string err;
 
@@ -398,6 +402,7 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
                 const int v = atoi(be);
                 if(v >= 1 && v <= 64) c->batch = (uint32_t)v;
             }
+            if(const char* me = getenv("PRT_MAX_PASS_BYTES")) c->passBytesMax = strtoull(me, nullptr, 10);
         }
         if(const char* g = getenv("PRT_GRID_BLOCKS_PER_CU"))
         {
@@ -1272,8 +1277,8 @@ static int render_ao(prt_context* c, uint32_t nsub = 1)
 {
     Pipe&       p  = c->pipes[0];
     hipStream_t st = c->stream;
-    if(nsub > 1)
     {
+        // (also for one iteration: a pass that could not be allocated leaves pipe 0 without buffers)
         const int rc = pipe_ensure(c, p, (size_t)c->npix * nsub, 0);
         if(rc) return rc;
     }
@@ -1319,19 +1324,42 @@ static int render_ao(prt_context* c, uint32_t nsub = 1)
 // One pass of pathRT.rgen (one aaRay of one vkCmdTraceRaysNV(W,H,1)): a fixed launch sequence on the pipe's
 // stream, then k_resolve on the main stream (iteration order). No host synchronisation.
 // buffers of one pipe for a pass over npass pixels with B bounces
+// Device bytes of a pipe's buffers per pixel of a pass with B bounces (pipe_alloc + the contrib planes)
+static size_t pass_bytes_per_pixel(int B)
+{
+    return 2 * 4 * sizeof(float4)      // rayO, rayD, hit, thr: two generations
+           + 3 * sizeof(float4)        // shO, shD, eiVis
+           + sizeof(float2) + 4 + 1 + 1  // aaOff, hitIds, dead, nvert
+           + 3 * 4                     // q[0], q[1], qShadow
+           + (size_t)(B + 1) * sizeof(float4);  // contrib[bounce]
+}
 static int pipe_ensure(prt_context* c, Pipe& p, size_t npass, int B)
 {
     if(p.allocated && p.cap >= npass && p.contribCap >= (uint32_t)B + 1u) return PRT_OK;
     if(p.allocated) HIPCHK(c, sync_all(c));
+    c->oom = false;
+    if(c->passBytesMax && npass > c->npix && (uint64_t)npass * pass_bytes_per_pixel(B) > c->passBytesMax)
+    {
+        c->oom = true;  // over the caller's bound: treated like an allocation that failed (prt_render shrinks the pass)
+        return fail(c, PRT_E_HIP, "pass of %zu pixels needs %zu bytes, limit %llu", npass, npass * pass_bytes_per_pixel(B),
+                    (unsigned long long)c->passBytesMax);
+    }
     const bool grow = p.cap < npass;
     hipError_t e    = pipe_alloc(p, npass);
-    if(e != hipSuccess) return fail(c, PRT_E_HIP, "pipe allocation failed: %s", hipGetErrorString(e));
-    if(grow || p.contribCap < (uint32_t)B + 1u)
+    if(e == hipSuccess && (grow || p.contribCap < (uint32_t)B + 1u))
     {
         dfree(p.contrib);
         p.contribCap = 0;
-        HIPCHK(c, dalloc(p.contrib, (size_t)(B + 1) * p.cap));
-        p.contribCap = (uint32_t)B + 1u;
+        e            = dalloc(p.contrib, (size_t)(B + 1) * p.cap);
+        if(e == hipSuccess) p.contribCap = (uint32_t)B + 1u;
+    }
+    if(e != hipSuccess)
+    {
+        // what was allocated goes back, so that a smaller pass can be tried; the runtime's sticky error is taken off
+        pipe_free_buffers(p);
+        c->oom = e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation;
+        (void)hipGetLastError();
+        return fail(c, PRT_E_HIP, "pipe allocation for %zu pixels failed: %s", npass, hipGetErrorString(e));
     }
     return PRT_OK;
 }
@@ -1499,30 +1527,41 @@ int prt_render(prt_context* c, int mode, uint32_t first, uint32_t n, uint32_t st
             HIPCHK(c, sync_all(c));
             c->lastMode = mode;
         }
-        while(n - k >= 2)
+        // Memory policy: a pass that cannot be allocated (hipErrorOutOfMemory, or more than prt_set_pass_memory_limit /
+        // PRT_MAX_PASS_BYTES allows) is retried with half the iterations, down to one iteration per pass — the one-by-one
+        // path below, whose buffers exist since prt_create. The size that fitted is remembered (batchFit).
+        uint32_t cap = c->batchFit ? (c->batchFit < c->batch ? c->batchFit : c->batch) : c->batch;
+        while(n - k >= 2 && cap >= 2)
         {
-            uint32_t nsub = n - k < c->batch ? n - k : c->batch;
+            uint32_t nsub = n - k < cap ? n - k : cap;
             if((uint64_t)c->npix * nsub >= (1ull << 31)) nsub = (uint32_t)(((1ull << 31) - 1) / c->npix);  // 32-bit pixel ids
             if(nsub < 2) break;
             c->ubo.iteration    = first + k * stride;
+            int rc;
             if(mode == PRT_MODE_AO)  // (AO.rgen takes nothing from the iteration number: the iterations of a pass are alike)
+                rc = render_ao(c, nsub);
+            else
             {
-                const int rc = render_ao(c, nsub);
-                if(rc) return rc;
-                c->iterations += nsub;
-                k += nsub;
+                // A large pass fills the GPU by itself: passes in flight on other streams add nothing then (measured at
+                // 1080p, 32 / 64 iterations per pass: 8170 / 8280 Mrays/s on one pipe, 8120 / 8250 on three), so such
+                // passes all run on pipe 0 and only that pipe's buffers grow to the pass size.
+                const bool large = (uint64_t)c->npix * nsub >= (24ull << 20);
+                rc               = render_path_pass(c, large ? 0 : c->nextPipe, 0, nsub, stride, !large);
+                if(rc == PRT_OK && !large) c->nextPipe = (c->nextPipe + 1) % c->nPipes;
+            }
+            if(rc != PRT_OK)
+            {
+                if(!c->oom) return rc;
+                c->oom      = false;
+                cap         = nsub / 2;
+                c->batchFit = cap < 1 ? 1 : cap;
                 continue;
             }
-            // A large pass fills the GPU by itself: passes in flight on other streams add nothing then (measured at
-            // 1080p, 32 / 64 iterations per pass: 8170 / 8280 Mrays/s on one pipe, 8120 / 8250 on three), so such
-            // passes all run on pipe 0 and only that pipe's buffers grow to the pass size.
-            const bool large = (uint64_t)c->npix * nsub >= (24ull << 20);
-            const int  rc    = render_path_pass(c, large ? 0 : c->nextPipe, 0, nsub, stride, !large);
-            if(rc) return rc;
-            if(!large) c->nextPipe = (c->nextPipe + 1) % c->nPipes;
+            c->batchUsed = nsub;
             c->iterations += nsub;
             k += nsub;
         }
+        if(k < n) c->batchUsed = c->batchUsed ? c->batchUsed : 1;
     }
     for(; k < n; ++k)
     {
@@ -1537,10 +1576,19 @@ int prt_set_iteration_batch(prt_context* c, int n)
 {
     if(!c) return PRT_E_INVALID;
     if(n < 1 || n > 64) return fail(c, PRT_E_LIMIT, "prt_set_iteration_batch: %d outside [1,64]", n);
-    c->batch = (uint32_t)n;
+    c->batch    = (uint32_t)n;
+    c->batchFit = 0;
     return PRT_OK;
 }
 int prt_get_iteration_batch(const prt_context* c) { return c ? (int)c->batch : PRT_E_INVALID; }
+int prt_get_pass_iterations(const prt_context* c) { return c ? (int)c->batchUsed : PRT_E_INVALID; }
+int prt_set_pass_memory_limit(prt_context* c, uint64_t bytes)
+{
+    if(!c) return PRT_E_INVALID;
+    c->passBytesMax = bytes;
+    c->batchFit     = 0;
+    return PRT_OK;
+}
 
 int prt_get_pipeline_depth(const prt_context* c) { return c ? c->nPipes : PRT_E_INVALID; }
 

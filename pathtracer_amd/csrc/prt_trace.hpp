@@ -34,7 +34,7 @@
 namespace prt {
 
 #ifndef PRT_LDS_STACK
-#define PRT_LDS_STACK 20
+#define PRT_LDS_STACK 12  // entries per lane in LDS (deeper ones: scratch); 12 + PRT_COLD_WORDS = 16 KiB per block of 256
 #endif
 // Loading a leaf's next triangle while the current one is tested costs 14 VGPRs = the sixth wave per SIMD. With
 // leaves of <= 2 triangles the sixth wave is worth more (measured: 2.33 -> 2.30 ms); with leaves of <= 4 it was not.
@@ -59,7 +59,10 @@ namespace prt {
 #define PRT_TRACE_BLOCK 256
 #endif
 #ifndef PRT_TRACE_WAVES
-#define PRT_TRACE_WAVES 6  // waves per SIMD the traversal kernels are compiled for (78 VGPRs; 6 x 20 KiB of LDS per CU)
+// waves per SIMD the traversal kernels are compiled for: 7 = 72 VGPRs (9 slab constants instead of 12, the cold part of the
+// ray state in LDS) and 7 x 22 KiB of LDS per CU. Round 3, same bench: 6 waves / 20 entries 13.67 ms per launch of
+// k_shadow_extend, 6 / 16 with the register diet 13.26, 7 / 12: 12.83.
+#define PRT_TRACE_WAVES 7
 #endif
 #define PRT_NODE_BYTES 64
 // The first PRT_TOP_NODES BVH4 nodes (numbered level by level: the top of the tree) are copied into LDS by every block.
@@ -68,9 +71,14 @@ namespace prt {
 // modes G / H: lanes that read a hot 85-record set through the L1 cost as much as lanes that miss; from LDS they cost
 // nothing there) — the L1's lane rate is what bounds the node phases.
 #ifndef PRT_TOP_NODES
-#define PRT_TOP_NODES 96  // 6 KiB: 6 blocks x (20 + 6) KiB = 156 of the CU's 160 KiB
+#define PRT_TOP_NODES 96  // 6 KiB: 7 blocks x (16 + 6) KiB = 154 of the CU's 160 KiB
 #endif
-#define PRT_TRACE_LDS_WORDS (PRT_LDS_STACK * PRT_TRACE_BLOCK + PRT_TOP_NODES * 16)
+// Per-lane LDS words of the traversal kernels: the stack entries, then the part of a ray's state that the node steps never
+// touch (trace_stream: the ray's tag and the best hit's prim / u / v, written when a closer hit is found and read when the
+// ray is finished) — four registers fewer in the loop that decides the occupancy.
+#define PRT_COLD_WORDS 4
+#define PRT_LANE_WORDS (PRT_LDS_STACK + PRT_COLD_WORDS)
+#define PRT_TRACE_LDS_WORDS (PRT_LANE_WORDS * PRT_TRACE_BLOCK + PRT_TOP_NODES * 16)
 #ifndef PRT_CHUNK
 #define PRT_CHUNK 256u  // rays per work-counter atomic: a device-scope atomic is a round trip to the memory side (64: 7.6 ms per launch, 128: 4.32, 256: 4.20, 512: 4.24, 1024: 4.33; eight per-XCD cursors or a static share of the queue: no better)
 #endif
@@ -133,8 +141,9 @@ struct RayCtx
     float    ox, oy, oz, tmin, tmax;
     float    Sx, Sy, Sz;  // shear of the watertight test
     int      kz;
-    float    rnx, rny, rnz, cnx, cny, cnz;  // near planes: t = fma(float(q), rn, cn)
-    float    rfx, rfy, rfz, cfx, cfy, cfz;  // far planes
+    // plane distance along an axis: t = fma(float(q), r, cn) for the near plane (the box grown by the pad),
+    // fma(float(q), r, cf) for the far one
+    float    rx, ry, rz, cnx, cny, cnz, cfx, cfy, cfz;
     bool     negx, negy, negz;              // direction sign: the near plane is max instead of min
 };
 
@@ -172,24 +181,24 @@ PRT_DEV void ray_prepare(const BvhView& bvh, f3 o, float tmin, f3 d, float tmax,
     amax       = gmax(amax, gabs(o.z));
     float pad = 3.814697265625e-06f * amax;
     if(TOP) pad = pad * bvh.padScale;  // top level of a two-level scene
-    // plane distance t = (qmin + q*qscale - (o +- pad)) * rd, widened by 2^-21, as one fma on float(q)
-#define PRT_SLAB_SETUP(c, k, rn, cn, rf, cf, ng)                     \
+    // plane distance t = (qmin + q*qscale - (o +- pad)) * rd as one fma on float(q). What the pad has to cover, in units of
+    // 2^-24 * amax along the axis (|plane - o| <= 2 amax): v_rcp_f32 (1 ulp, a common factor of both terms) 4, the
+    // roundings of r, of the two sums and the product in c, and of the fma 2 + 1 + 2 + 2 + 2 = 13 in all, and the 16 by
+    // which tri_core lets a hit point lie outside its triangle's extent: 29 of the pad's 64.
+#define PRT_SLAB_SETUP(c, k, rr, cn, cf, ng)                         \
     {                                                                \
         float dk = d.c;                                              \
         if(gabs(dk) < 1e-20f) dk = (dk < 0.0f) ? -1e-20f : 1e-20f;   \
         const float rd  = __builtin_amdgcn_rcpf(dk);                 \
         ng              = dk < 0.0f;                                 \
         const float sp  = ng ? -pad : pad;                           \
-        const float r0  = rd * 0.99999952f;                          \
-        const float r1  = rd * 1.00000048f;                          \
-        cn              = (bvh.qmin[k] - (o.c + sp)) * r0;           \
-        cf              = (bvh.qmin[k] - (o.c - sp)) * r1;           \
-        rn              = r0 * bvh.qscale[k];                        \
-        rf              = r1 * bvh.qscale[k];                        \
+        cn              = (bvh.qmin[k] - (o.c + sp)) * rd;           \
+        cf              = (bvh.qmin[k] - (o.c - sp)) * rd;           \
+        rr              = rd * bvh.qscale[k];                        \
     }
-    PRT_SLAB_SETUP(x, 0, r.rnx, r.cnx, r.rfx, r.cfx, r.negx)
-    PRT_SLAB_SETUP(y, 1, r.rny, r.cny, r.rfy, r.cfy, r.negy)
-    PRT_SLAB_SETUP(z, 2, r.rnz, r.cnz, r.rfz, r.cfz, r.negz)
+    PRT_SLAB_SETUP(x, 0, r.rx, r.cnx, r.cfx, r.negx)
+    PRT_SLAB_SETUP(y, 1, r.ry, r.cny, r.cfy, r.negy)
+    PRT_SLAB_SETUP(z, 2, r.rz, r.cnz, r.cfz, r.negz)
 #undef PRT_SLAB_SETUP
 }
 
@@ -382,12 +391,12 @@ PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_
 #define PRT_QHI(w) ((float)((w) >> 16))
 #define PRT_SLAB(Q, nxw, nyw, nzw, fxw, fyw, fzw, key)                                                               \
     {                                                                                                                \
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(Q(nxw), r.rnx, r.cnx),                      \
-                                                         __builtin_fmaf(Q(nyw), r.rny, r.cny)),                     \
-                                         __builtin_fmaxf(__builtin_fmaf(Q(nzw), r.rnz, r.cnz), r.tmin));            \
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(Q(fxw), r.rfx, r.cfx),                      \
-                                                         __builtin_fmaf(Q(fyw), r.rfy, r.cfy)),                     \
-                                         __builtin_fminf(__builtin_fmaf(Q(fzw), r.rfz, r.cfz), tbest));             \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(Q(nxw), r.rx, r.cnx),                       \
+                                                         __builtin_fmaf(Q(nyw), r.ry, r.cny)),                      \
+                                         __builtin_fmaxf(__builtin_fmaf(Q(nzw), r.rz, r.cnz), r.tmin));             \
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(Q(fxw), r.rx, r.cfx),                       \
+                                                         __builtin_fmaf(Q(fyw), r.ry, r.cfy)),                      \
+                                         __builtin_fminf(__builtin_fmaf(Q(fzw), r.rz, r.cfz), tbest));              \
         key = (tn <= tf) ? tn : inf;                                                                                 \
     }
     float t0, t1, t2, t3;
@@ -438,27 +447,43 @@ PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_
 // slot: rows (A | id0), (B | id1), (C | -), (D | -). Same floats into the same arithmetic as two separate tests: the corners
 // are sheared once each, and the second triangle's third edge function B'.x*A'.y - B'.y*A'.x = C.x*A.y - C.y*A.x is
 // exactly -(A.x*C.y - A.y*C.x), the first one's second (products commute, a - b = -(b - a) in IEEE arithmetic).
-template <bool ANY>
-PRT_DEV bool leaf_hit(Hit& best, float tt, float uu, float vv, uint32_t p)
+#define PRT_COLD_AT(lds, j) PRT_STACK_AT(lds, PRT_LDS_STACK + (j))  // 0: tag, 1: prim, 2: u, 3: v
+// COLD: prim / u / v of the best hit live in the lane's LDS words (trace_stream), only t stays in a register.
+template <bool ANY, bool COLD>
+PRT_DEV bool leaf_hit(Hit& best, uint32_t* lds, float tt, float uu, float vv, uint32_t p)
 {
     if(ANY)
     {
-        best.prim = p;
-        best.t    = tt;
+        if(COLD)
+            PRT_COLD_AT(lds, 1) = p;
+        else
+            best.prim = p;
+        best.t = tt;
         return true;
     }
-    if(tt < best.t || (tt == best.t && p < best.prim))
+    bool closer = tt < best.t;
+    if(tt == best.t) closer = p < (COLD ? PRT_COLD_AT(lds, 1) : best.prim);
+    if(closer)
     {
-        best.t    = tt;
-        best.u    = uu;
-        best.v    = vv;
-        best.prim = p;
+        best.t = tt;
+        if(COLD)
+        {
+            PRT_COLD_AT(lds, 1) = p;
+            PRT_COLD_AT(lds, 2) = __float_as_uint(uu);
+            PRT_COLD_AT(lds, 3) = __float_as_uint(vv);
+        }
+        else
+        {
+            best.u    = uu;
+            best.v    = vv;
+            best.prim = p;
+        }
     }
     return false;
 }
-template <bool ANY, bool INSTR>
+template <bool ANY, bool INSTR, bool COLD = false>
 PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit& best, TraceCount& tc, float sceneAbs,
-                       uint32_t primBase)
+                       uint32_t primBase, uint32_t* lds = nullptr)
 {
     const uint32_t ref   = ~(uint32_t)leafRef;
     const uint32_t first = ref >> 3, count = ref & 7u;
@@ -479,7 +504,7 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
         float        tt, uu, vv;
         if(INSTR) tc.tris++;
         if(tri_core(r, sceneAbs, A, B, C, U0, V0, W0, tt, uu, vv))
-            if(leaf_hit<ANY>(best, tt, uu, vv, primBase + (uint32_t)__float_as_int(qa.w))) return true;
+            if(leaf_hit<ANY, COLD>(best, lds, tt, uu, vv, primBase + (uint32_t)__float_as_int(qa.w))) return true;
         if(count == 1u) return false;
         TriVtx   A1, B1, C1;
         float    W1;
@@ -505,7 +530,7 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
         const float V1 = A1.x * C1.y - A1.y * C1.x;
         if(INSTR) tc.tris++;
         if(tri_core(r, sceneAbs, A1, B1, C1, U1, V1, W1, tt, uu, vv))
-            if(leaf_hit<ANY>(best, tt, uu, vv, primBase + id1)) return true;
+            if(leaf_hit<ANY, COLD>(best, lds, tt, uu, vv, primBase + id1)) return true;
         return false;
     }
 #else
@@ -529,7 +554,7 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
         float tt, uu, vv;
         if(INSTR) tc.tris++;
         if(tri_test(r, sceneAbs, a, b, c, tt, uu, vv))
-            if(leaf_hit<ANY>(best, tt, uu, vv, primBase + (uint32_t)__float_as_int(a.w))) return true;
+            if(leaf_hit<ANY, COLD>(best, lds, tt, uu, vv, primBase + (uint32_t)__float_as_int(a.w))) return true;
 #if PRT_TRI_PREFETCH
         a = na;
         b = nb;
@@ -552,7 +577,7 @@ PRT_DEV Hit hit_none(float tmax)
 // Copies the top of the tree into the block's LDS (behind the stacks) and returns it; all threads of the block call it.
 PRT_DEV const uint4* stage_top_nodes(const BvhView& bvh, uint32_t* ldsBase)
 {
-    uint4* top = (uint4*)(ldsBase + PRT_LDS_STACK * PRT_TRACE_BLOCK);
+    uint4* top = (uint4*)(ldsBase + PRT_LANE_WORDS * PRT_TRACE_BLOCK);
     if(PRT_TOP_NODES)
     {
         for(uint32_t k = threadIdx.x; k < bvh.nTop * 4u; k += PRT_TRACE_BLOCK) top[k] = bvh.nodes[k];
@@ -672,8 +697,8 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
     int                      sp = 1;
     int32_t                  spill[TWO ? PRT_SPILL_STACK_TWO : PRT_SPILL_STACK];
     RayCtx                   r;
-    Hit                      best = hit_none(0.0f);
-    uint32_t                 tag  = 0;
+    Hit                      best = hit_none(0.0f);  // only best.t is used: prim / u / v are PRT_COLD_AT words
+    uint32_t                 nskip = 0;              // wave-uniform
     // two-level scenes: the structure the lane is in
     float                    curAbs   = bvh.sceneAbs;
     uint32_t                 primBase = 0;
@@ -722,13 +747,19 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
                 tc.wSetup++;
                 tc.lSetup += take;
             }
+            bool counted = true;
             if(!active && rank < take)
             {
-                f3    o, d;
-                float tmin, tmax;
-                if(!io.load(chunkPos + rank, o, tmin, d, tmax, tag)) nskipped++;
+                f3       o, d;
+                float    tmin, tmax;
+                uint32_t tag;
+                counted = io.load(chunkPos + rank, o, tmin, d, tmax, tag);
                 ray_prepare<TWO>(bvh, o, tmin, d, tmax, r);
-                best   = hit_none(tmax);
+                best.t = tmax;
+                PRT_COLD_AT(lds, 0) = tag;
+                PRT_COLD_AT(lds, 1) = 0xffffffffu;
+                PRT_COLD_AT(lds, 2) = 0u;
+                PRT_COLD_AT(lds, 3) = 0u;
                 cur    = bvh.root;
                 leaf   = kEmptyLeaf;
                 sp     = 1;
@@ -741,6 +772,7 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
                     wtmin  = tmin;
                 }
             }
+            nskip += (uint32_t)__popcll(__ballot(!counted));
             chunkPos += take;
         }
         const uint32_t nActive = (uint32_t)__popcll(__ballot(active));
@@ -816,7 +848,7 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
             }
             if(has)
             {
-                const bool occluded = leaf_test<ANY, INSTR>(bvh, r, leaf, best, tc, TWO ? curAbs : bvh.sceneAbs, TWO ? primBase : 0u);
+                const bool occluded = leaf_test<ANY, INSTR, true>(bvh, r, leaf, best, tc, TWO ? curAbs : bvh.sceneAbs, TWO ? primBase : 0u, lds);
                 leaf                = kEmptyLeaf;
                 if(ANY && occluded)
                 {
@@ -858,11 +890,17 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
         // ---- finished rays
         if(active && cur == kSentinel && leaf == kEmptyLeaf)
         {
-            io.store(tag, best);
+            Hit h;
+            h.prim = PRT_COLD_AT(lds, 1);
+            h.u    = __uint_as_float(PRT_COLD_AT(lds, 2));
+            h.v    = __uint_as_float(PRT_COLD_AT(lds, 3));
+            h.t    = best.t;
+            io.store(PRT_COLD_AT(lds, 0), h);
             active = false;
         }
         PRT_LAP(cTri)
     }
+    if(lane == 0) nskipped += nskip;  // the callers sum it over the wave
     if(overrun) tc.overrun = 1u;
     if(INSTR) tc.cTotal += (uint32_t)(__builtin_amdgcn_s_memtime() - tStart);
 #undef PRT_LAP

@@ -609,3 +609,37 @@ def test_full_size_properties(conference_full):
     num = ((s0 + s1 - a)[..., :3] ** 2).mean()
     den = (a[..., :3] ** 2).mean()
     assert num / den < 1e-10
+
+
+@pytest.mark.gpu
+def test_render_degrades_when_a_pass_does_not_fit():
+    """Memory policy of prt_render: a pass whose buffers cannot be had (here: more than prt_set_pass_memory_limit allows —
+    the same path a hipErrorOutOfMemory takes) is retried with half the iterations, down to one per pass; the image and
+    the ray count are those of the unlimited render, and prt_get_pass_iterations reports the batch that was used.
+    AO, whose one-iteration form shares pipe 0's buffers, keeps working after a pass that did not fit."""
+    sc = scenes.conference_room(detail=0.3)
+    W, H = 160, 96
+    per_px = 218 + 16 * 3  # bytes per pixel and iteration at 3 bounces (prt.h)
+    ref = None
+    for limit, want in ((0, 8), (W * H * per_px * 5, 4), (W * H * per_px * 2 + 64, 2), (1, 1)):
+        with capi.Context(W, H) as ctx:
+            ctx.set_scene(sc)
+            ctx.set_seed(4)
+            ctx.build_accel()
+            ctx.set_iteration_batch(8)
+            ctx.set_pass_memory_limit(limit)
+            ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=3))
+            assert ctx.pass_iterations() == 0
+            ctx.render(capi.MODE_PATH, 1, 16, 1)
+            assert ctx.pass_iterations() == want
+            got = (ctx.read_accum().tobytes(), ctx.stats().rays, ctx.stats().iterations)
+            if ref is None:
+                ref = got
+            assert got == ref
+            # AO after a refused pass: batched (refused again, then smaller) and one iteration per call
+            ctx.clear_accum()
+            ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, ao_rays=4))
+            ctx.render(capi.MODE_AO, 1, 6, 1)
+            ctx.render_iteration(capi.MODE_AO)
+            ao = ctx.read_accum()
+            assert np.isfinite(ao).all() and (ao[..., 3] == 7.0).all()
