@@ -190,6 +190,8 @@ def main():
     if rank == 0:
         log(f"[bench] scene {scene['name']}: {ntri} triangles, BVH {st.bvh_nodes} nodes depth {st.bvh_depth} "
             f"built on GPU in {st.bvh_build_ms:.1f} ms (setup {time.time() - t0:.1f} s)")
+    workload = (f"{scene['name']} ({args.scene}-scale), {ntri} triangles, {W}x{H}, path tracing, {args.bounces} bounces"
+                f"{' + Russian roulette' if args.rr else ''}, GGX + area-light NEE, 1 spp per step")
     ubo = uniforms.make_uniforms(scene, W, H, bounces=args.bounces, spp=1024, iteration=1, light_area=light_area)
     ctx.set_uniforms(ubo)
     ctx.set_flags(capi.FLAG_RUSSIAN_ROULETTE if args.rr else 0)  # additive accumulation: required for the multi-GPU sum
@@ -319,22 +321,33 @@ def main():
         traffic = src = None
         binding = {}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                allk = json.load(open(pmc))
-                t = allk.get(kname.split(" ")[0], {})
+        try:
+            from pathtracer_amd.buildinfo import kernel_source_hash
+
+            allk = json.load(open(pmc))
+            ent = allk.get("scenes", {}).get(args.scene)
+            if allk.get("kernel_source_hash") != kernel_source_hash():
+                src = (f"none: profiles/pmc_traffic.json was measured on kernel sources {allk.get('kernel_source_hash')}, this "
+                       f"tree is {kernel_source_hash()} (re-run tools/profile.sh + tools/summarize_profile.py)")
+            elif ent is None or ent.get("workload") != workload:
+                src = (f"none: profiles/pmc_traffic.json holds no counters for this workload ({workload!r}); it has "
+                       f"{sorted(allk.get('scenes', {}))}")
+            else:
+                t = ent["kernels"].get(kname.split(" ")[0], {})
                 if t.get("hbm_bytes_per_ray"):
                     traffic = int(t["hbm_bytes_per_ray"] * n1)
-                    src = (f"profiles/pmc_traffic.json [{allk.get('_tag', '?')}]: (FETCH_SIZE x {t.get('fetch_correction', 2)} + WRITE_SIZE) "
+                    src = (f"profiles/pmc_traffic.json scenes[{args.scene!r}] [{ent.get('tag', '?')}, kernel sources "
+                           f"{allk['kernel_source_hash']}]: (FETCH_SIZE x {t.get('fetch_correction', 2)} + WRITE_SIZE) "
                            f"per ray = {t['hbm_bytes_per_ray']} B at {t.get('rays_per_launch')} rays per launch, scaled to this run's "
                            f"{n1:.0f} rays per launch; counted at the L2's fabric side, so Infinity-Cache hits are included "
                            f"(upper bound on HBM bytes)")
                 for key in ("l2_hit_rate", "valu_busy_simd", "valu_active_per_wave_cycle", "wait_any_per_wave_cycle",
-                            "tcp_tcc_read_req_per_ray", "l1_miss_lines_per_clk_per_cu", "l1_miss_ceiling_lines_per_clk_per_cu"):
+                            "tcp_tcc_read_req_per_ray", "tcp_tcc_read_latency_cycles", "l1_miss_lines_per_clk_per_cu",
+                            "l1_miss_ceiling_lines_per_clk_per_cu", "verdict"):
                     if key in t:
                         binding[key] = t[key]
-            except Exception:
-                traffic = src = None
+        except Exception as e:  # noqa: BLE001
+            traffic, src = None, f"none: {e}"
         st2 = prof2.closest_steps if kind == capi.K_EXTEND else prof2.any_steps if kind == capi.K_SHADOW else None
         def lanes(sx):
             return {"node_steps": round(sx.node_lanes / max(1, 64 * sx.node_steps), 3),
@@ -344,7 +357,7 @@ def main():
                                        if st2 is None else lanes(st2))
         binding["what"] = ("not HBM: the kernel is bound by the latency of dependent, divergent 16-byte gathers (one L2 / "
                            "Infinity-Cache round trip per node visit below the part of the tree that is staged in LDS, the wave "
-                           "waits for its slowest lane) at the 6 waves per SIMD its registers allow; DESIGN.md section 5")
+                           "waits for its slowest lane) at the 7 waves per SIMD its registers and LDS allow; DESIGN.md section 5")
         achieved = traffic / (ms1 * 1e-3) / 1e9 if traffic and ms1 > 0 else None
         roofline = {"bound": "hbm", "kernel": kname,
                     "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -401,9 +414,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": f"synthetic (procedural {args.scene}-scale scene; the reference's scenes are not in its repo)",
-            "config": {"workload": f"{scene['name']} ({args.scene}-scale), {ntri} triangles, {W}x{H}, path tracing, "
-                                   f"{args.bounces} bounces{' + Russian roulette' if args.rr else ''}, GGX + area-light NEE, "
-                                   f"1 spp per step",
+            "config": {"workload": workload,
                        "triangles": ntri, "width": W, "height": H, "bounces": args.bounces,
                        "iterations_per_gpu": K, "parallelism": f"spp-sharded x{n_gpus}" if n_gpus > 1 else "single GPU",
                        "rays_total": int(total_rays), "rays_per_sample": round(total_rays / (K * n_gpus * W * H), 3),
