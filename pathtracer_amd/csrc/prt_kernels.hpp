@@ -314,15 +314,15 @@ struct ExtendIO
 #define PRT_TRACE_ATTR
 #endif
 #ifndef PRT_TRACE_WAVES_TWO
-#define PRT_TRACE_WAVES_TWO 5  // waves per SIMD of the two-level traversal kernels (96 VGPRs; measured 4: 3470, 5: 3730, 6: 3280 Mrays/s)
+#define PRT_TRACE_WAVES_TWO 6  // waves per SIMD of the two-level traversal kernels (80 VGPRs since the register diet of round 3: 5: 3300, 6: 3510 Mrays/s on the 2 001-instance scene)
 #endif
 template <bool INSTR, bool TWO = false>
 __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : (TWO ? PRT_TRACE_WAVES_TWO : PRT_TRACE_WAVES)) PRT_TRACE_ATTR k_extend(SceneView sc, FrameView f, uint32_t generation,
                                                             const uint32_t* __restrict__ countPtr,
                                                             uint32_t* workCtr, uint32_t primary, TraceTune tune)
 {
-    __shared__ __align__(16) uint32_t stackLds[PRT_TRACE_LDS_WORDS];
-    const uint4* topLds = stage_top_nodes(sc.bvh, stackLds);
+    __shared__ __align__(16) uint32_t stackLds[TWO ? PRT_TRACE_LDS_WORDS_TWO : PRT_TRACE_LDS_WORDS];
+    const uint4* topLds = stage_top_nodes<PRT_LS(TWO)>(sc.bvh, stackLds);
     const uint32_t      count = countPtr ? *countPtr : f.npix;
     uint32_t            nskip = 0;
     TraceCount          tc    = {};
@@ -812,8 +812,8 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : (TWO ? PRT_TRACE_
                                                             const uint32_t* __restrict__ countPtr, uint32_t* workCtr,
                                                             uint32_t bounce, TraceTune tune)
 {
-    __shared__ __align__(16) uint32_t stackLds[PRT_TRACE_LDS_WORDS];
-    const uint4* topLds = stage_top_nodes(sc.bvh, stackLds);
+    __shared__ __align__(16) uint32_t stackLds[TWO ? PRT_TRACE_LDS_WORDS_TWO : PRT_TRACE_LDS_WORDS];
+    const uint4* topLds = stage_top_nodes<PRT_LS(TWO)>(sc.bvh, stackLds);
     const uint32_t      count = *countPtr;
     uint32_t            nskip = 0;
     TraceCount          tc    = {};
@@ -831,8 +831,8 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, INSTR ? 4 : (TWO ? PRT_TRACE_
     SceneView sc, FrameView f, const uint32_t* __restrict__ shCountPtr, uint32_t* shWork, uint32_t bounce,
     const uint32_t* __restrict__ exCountPtr, uint32_t* exWork, TraceTune tune)
 {
-    __shared__ __align__(16) uint32_t stackLds[PRT_TRACE_LDS_WORDS];
-    const uint4* topLds = stage_top_nodes(sc.bvh, stackLds);
+    __shared__ __align__(16) uint32_t stackLds[TWO ? PRT_TRACE_LDS_WORDS_TWO : PRT_TRACE_LDS_WORDS];
+    const uint4* topLds = stage_top_nodes<PRT_LS(TWO)>(sc.bvh, stackLds);
     {
         const uint32_t count = *exCountPtr;
         uint32_t       nskip = 0;
@@ -896,11 +896,11 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK) k_ao_shade(SceneView sc, Fram
                                                               uint32_t flags, uint32_t* workCtr)
 {
     const prt_uniforms* ubo = &ubo_;
-    __shared__ __align__(16) uint32_t stackLds[PRT_TRACE_LDS_WORDS];
+    __shared__ __align__(16) uint32_t stackLds[TWO ? PRT_TRACE_LDS_WORDS_TWO : PRT_TRACE_LDS_WORDS];
     // Sobol byte tables of dimensions 0 and 1 (sobol1D_bytes: four reads instead of the 32-step loop, same bits)
     __shared__ uint32_t sobT[2 * 1024];
     for(uint32_t k = threadIdx.x; k < 2u * 1024u; k += PRT_TRACE_BLOCK) sobT[k] = sc.sobolBytes[k];
-    const uint4* topLds = stage_top_nodes(sc.bvh, stackLds);  // (its barrier covers sobT as well)
+    const uint4* topLds = stage_top_nodes<PRT_LS(TWO)>(sc.bvh, stackLds);  // (its barrier covers sobT as well)
     __syncthreads();
     const uint32_t      count   = f.npix;
     const int           lane    = threadIdx.x & 63;
@@ -1047,8 +1047,8 @@ __global__ void __launch_bounds__(PRT_TRACE_BLOCK, TWO ? PRT_TRACE_WAVES_TWO : P
                                                                  uint32_t* workCtr, TraceTune tune,
                                                                  unsigned long long* stats)
 {
-    __shared__ __align__(16) uint32_t stackLds[PRT_TRACE_LDS_WORDS];
-    const uint4* topLds = stage_top_nodes(bvh, stackLds);
+    __shared__ __align__(16) uint32_t stackLds[TWO ? PRT_TRACE_LDS_WORDS_TWO : PRT_TRACE_LDS_WORDS];
+    const uint4* topLds = stage_top_nodes<PRT_LS(TWO)>(bvh, stackLds);
     uint32_t            nskip = 0;
     TraceCount          tc    = {};
     BatchIO             io{rays, hits};

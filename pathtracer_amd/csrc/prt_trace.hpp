@@ -36,6 +36,9 @@ namespace prt {
 #ifndef PRT_LDS_STACK
 #define PRT_LDS_STACK 12  // entries per lane in LDS (deeper ones: scratch); 12 + PRT_COLD_WORDS = 16 KiB per block of 256
 #endif
+#ifndef PRT_LDS_STACK_TWO
+#define PRT_LDS_STACK_TWO 16  // two-level kernels (6 waves per SIMD: 6 x (20 + 6) KiB; top-level entries + marker + the structure's)
+#endif
 // Loading a leaf's next triangle while the current one is tested costs 14 VGPRs = the sixth wave per SIMD. With
 // leaves of <= 2 triangles the sixth wave is worth more (measured: 2.33 -> 2.30 ms); with leaves of <= 4 it was not.
 #ifndef PRT_TRI_PREFETCH
@@ -77,20 +80,23 @@ namespace prt {
 // touch (trace_stream: the ray's tag and the best hit's prim / u / v, written when a closer hit is found and read when the
 // ray is finished) — four registers fewer in the loop that decides the occupancy.
 #define PRT_COLD_WORDS 4
-#define PRT_LANE_WORDS (PRT_LDS_STACK + PRT_COLD_WORDS)
-#define PRT_TRACE_LDS_WORDS (PRT_LANE_WORDS * PRT_TRACE_BLOCK + PRT_TOP_NODES * 16)
+#define PRT_TRACE_LDS_WORDS_OF(ls) (((ls) + PRT_COLD_WORDS) * PRT_TRACE_BLOCK + PRT_TOP_NODES * 16)
+#define PRT_TRACE_LDS_WORDS PRT_TRACE_LDS_WORDS_OF(PRT_LDS_STACK)
+#define PRT_TRACE_LDS_WORDS_TWO PRT_TRACE_LDS_WORDS_OF(PRT_LDS_STACK_TWO)
+// LDS stack entries of an instantiation
+#define PRT_LS(two) ((two) ? PRT_LDS_STACK_TWO : PRT_LDS_STACK)
 #ifndef PRT_CHUNK
 #define PRT_CHUNK 256u  // rays per work-counter atomic: a device-scope atomic is a round trip to the memory side (64: 7.6 ms per launch, 128: 4.32, 256: 4.20, 512: 4.24, 1024: 4.33; eight per-XCD cursors or a static share of the queue: no better)
 #endif
 
-static_assert(1 + 3 * (PRT_MAX_DEPTH / 2 + 1) <= PRT_LDS_STACK + PRT_SPILL_STACK && PRT_LDS_STACK >= 8, "stack covers the deepest tree");
+static_assert(1 + 3 * (PRT_MAX_DEPTH / 2 + 1) <= PRT_LDS_STACK + PRT_SPILL_STACK && PRT_LDS_STACK >= 8 && PRT_LDS_STACK_TWO >= 8, "stack covers the deepest tree");
 
 constexpr int32_t kSentinel  = 0x7fffffff;  // bottom-of-stack marker: the ray is finished
 constexpr int32_t kInstExit  = 0x7ffffffe;  // two-level scenes: the entries above this one belong to an instance
 constexpr int32_t kEmptyLeaf = -1;          // ~0: leaf reference with count 0
 // two-level scenes: the top-level tree is limited to 32 binary levels (<= 51 stack entries), + 1 exit marker
 #define PRT_TLAS_MAX_DEPTH 32
-#define PRT_SPILL_STACK_TWO (PRT_SPILL_STACK + 3 * (PRT_TLAS_MAX_DEPTH / 2 + 1) + 1)
+#define PRT_SPILL_STACK_TWO (100 - PRT_LDS_STACK_TWO + 3 * (PRT_TLAS_MAX_DEPTH / 2 + 1) + 1)
 
 struct BvhView
 {
@@ -282,29 +288,31 @@ PRT_DEV bool tri_test(const RayCtx& r, float sceneAbs, float4 q0, float4 q1, flo
 }
 
 // ---- per-lane stack: LDS [entry][thread] + scratch spill --------------------------------------------
-#define PRT_STACK_AT(lds, i) (lds)[(i) * PRT_TRACE_BLOCK]
+#define PRT_STACK_AT(lds, i) (lds)[((i) + PRT_COLD_WORDS) * PRT_TRACE_BLOCK]  // the lane's cold words come first
 
+template <int LS>
 PRT_DEV int32_t stack_pop(int& sp, const uint32_t* lds, const int32_t* spill)
 {
     --sp;
     int32_t v;
-    if(__builtin_expect(sp < PRT_LDS_STACK, 1))
+    if(__builtin_expect(sp < LS, 1))
         v = (int32_t)PRT_STACK_AT(lds, sp);
     else
     {
-        v = spill[sp - PRT_LDS_STACK];
+        v = spill[sp - LS];
         asm volatile("" : "+v"(v));  // keeps the two loads apart: ds_read / scratch_load, not one flat load
     }
     return v;
 }
+template <int LS>
 PRT_DEV void stack_push_slow(int& sp, uint32_t* lds, int32_t* spill, int32_t v)
 {
-    if(sp < PRT_LDS_STACK)
+    if(sp < LS)
         PRT_STACK_AT(lds, sp) = (uint32_t)v;
     else
     {
         asm volatile("" ::: "memory");
-        spill[sp - PRT_LDS_STACK] = v;
+        spill[sp - LS] = v;
     }
     ++sp;
 }
@@ -321,7 +329,7 @@ PRT_DEV void stack_push_slow(int& sp, uint32_t* lds, int32_t* spill, int32_t v)
 
 // One BVH4 node: four slab tests, nearest hit child becomes `cur`, the others are pushed (farthest
 // first). No hit: pop. ANY rays skip the distance sort.
-template <bool ANY>
+template <bool ANY, int LS>
 PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_t& cur, int& sp, uint32_t* lds,
                         int32_t* spill, const uint4* top)
 {
@@ -417,7 +425,7 @@ PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_
         PRT_CE(t1, r1, t2, r2)
     }
     const bool v0 = t0 < inf, v1 = t1 < inf, v2 = t2 < inf, v3 = t3 < inf;
-    if(__builtin_expect(sp + 3 <= PRT_LDS_STACK, 1))
+    if(__builtin_expect(sp + 3 <= LS, 1))
     {
         PRT_STACK_AT(lds, sp) = (uint32_t)r3;
         sp += v3 ? 1 : 0;
@@ -428,14 +436,14 @@ PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_
     }
     else
     {
-        if(v3) stack_push_slow(sp, lds, spill, r3);
-        if(v2) stack_push_slow(sp, lds, spill, r2);
-        if(v1) stack_push_slow(sp, lds, spill, r1);
+        if(v3) stack_push_slow<LS>(sp, lds, spill, r3);
+        if(v2) stack_push_slow<LS>(sp, lds, spill, r2);
+        if(v1) stack_push_slow<LS>(sp, lds, spill, r1);
     }
     if(v0)
         cur = r0;
     else
-        cur = stack_pop(sp, lds, spill);
+        cur = stack_pop<LS>(sp, lds, spill);
 }
 
 // All triangles of one leaf. Returns true when an ANY ray found an occluder.
@@ -447,7 +455,7 @@ PRT_DEV void node4_step(const BvhView& bvh, const RayCtx& r, float tbest, int32_
 // slot: rows (A | id0), (B | id1), (C | -), (D | -). Same floats into the same arithmetic as two separate tests: the corners
 // are sheared once each, and the second triangle's third edge function B'.x*A'.y - B'.y*A'.x = C.x*A.y - C.y*A.x is
 // exactly -(A.x*C.y - A.y*C.x), the first one's second (products commute, a - b = -(b - a) in IEEE arithmetic).
-#define PRT_COLD_AT(lds, j) PRT_STACK_AT(lds, PRT_LDS_STACK + (j))  // 0: tag, 1: prim, 2: u, 3: v
+#define PRT_COLD_AT(lds, j) (lds)[(j) * PRT_TRACE_BLOCK]  // 0: tag, 1: prim, 2: u, 3: v
 // COLD: prim / u / v of the best hit live in the lane's LDS words (trace_stream), only t stays in a register.
 template <bool ANY, bool COLD>
 PRT_DEV bool leaf_hit(Hit& best, uint32_t* lds, float tt, float uu, float vv, uint32_t p)
@@ -575,9 +583,10 @@ PRT_DEV Hit hit_none(float tmax)
 }
 
 // Copies the top of the tree into the block's LDS (behind the stacks) and returns it; all threads of the block call it.
+template <int LS = PRT_LDS_STACK>
 PRT_DEV const uint4* stage_top_nodes(const BvhView& bvh, uint32_t* ldsBase)
 {
-    uint4* top = (uint4*)(ldsBase + PRT_LANE_WORDS * PRT_TRACE_BLOCK);
+    uint4* top = (uint4*)(ldsBase + (LS + PRT_COLD_WORDS) * PRT_TRACE_BLOCK);
     if(PRT_TOP_NODES)
     {
         for(uint32_t k = threadIdx.x; k < bvh.nTop * 4u; k += PRT_TRACE_BLOCK) top[k] = bvh.nodes[k];
@@ -623,6 +632,7 @@ template <bool ANY, bool INSTR = false, bool TWO = false>
 PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, const uint4* top, f3 o, float tmin, f3 d, float tmax,
                       TraceCount* tcp = nullptr)
 {
+    constexpr int LS = PRT_LS(TWO);
     RayCtx r;
     ray_prepare<TWO>(bvh, o, tmin, d, tmax, r);
     Hit        best = hit_none(tmax);
@@ -642,17 +652,17 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, const uint4* top, f3 o,
             {
                 ray_prepare<true>(bvh, o, tmin, d, tmax, r);
                 inInst = false;
-                cur    = stack_pop(sp, lds, spill);
+                cur    = stack_pop<LS>(sp, lds, spill);
                 continue;
             }
             if(cur < 0 && !inInst)
             {
                 const int32_t root = instance_enter(bvh, cur, o, tmin, d, tmax, r, curAbs, primBase);
                 if(root == kEmptyLeaf)
-                    cur = stack_pop(sp, lds, spill);
+                    cur = stack_pop<LS>(sp, lds, spill);
                 else
                 {
-                    stack_push_slow(sp, lds, spill, kInstExit);
+                    stack_push_slow<LS>(sp, lds, spill, kInstExit);
                     inInst = true;
                     cur    = root;
                 }
@@ -662,12 +672,12 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, const uint4* top, f3 o,
         if(cur >= 0)
         {
             if(INSTR) tc.nodes++;
-            node4_step<ANY>(bvh, r, best.t, cur, sp, lds, spill, top);
+            node4_step<ANY, LS>(bvh, r, best.t, cur, sp, lds, spill, top);
         }
         else
         {
             if(leaf_test<ANY, INSTR>(bvh, r, cur, best, tc, TWO ? curAbs : bvh.sceneAbs, TWO ? primBase : 0u)) break;
-            cur = stack_pop(sp, lds, spill);
+            cur = stack_pop<LS>(sp, lds, spill);
         }
     }
     if(INSTR && tcp)
@@ -688,6 +698,7 @@ template <bool ANY, bool INSTR, class IO, bool TWO = false>
 PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, uint32_t count, uint32_t* workCtr,
                           const TraceTune tune, IO& io, uint32_t& nskipped, TraceCount& tc)
 {
+    constexpr int            LS     = PRT_LS(TWO);
     const int                lane   = threadIdx.x & 63;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     uint32_t                 chunkPos = 0, chunkEnd = 0;  // wave-uniform
@@ -803,11 +814,11 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
             if(active && (uint32_t)cur < (uint32_t)kStepEnd)
             {
                 if(INSTR) tc.nodes++;
-                node4_step<ANY>(bvh, r, best.t, cur, sp, lds, spill, top);
+                node4_step<ANY, LS>(bvh, r, best.t, cur, sp, lds, spill, top);
                 if(cur < 0 && leaf == kEmptyLeaf && (!TWO || inInst))
                 {
                     leaf = cur;
-                    cur  = stack_pop(sp, lds, spill);
+                    cur  = stack_pop<LS>(sp, lds, spill);
                 }
             }
             // lanes that can go on in this phase: at an inner node (two-level: lanes about to enter or leave an instance
@@ -821,7 +832,7 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
         if(active && leaf == kEmptyLeaf && cur < 0 && (!TWO || inInst))
         {
             leaf = cur;
-            cur  = stack_pop(sp, lds, spill);
+            cur  = stack_pop<LS>(sp, lds, spill);
         }
         for(uint32_t round = 0;; ++round)
         {
@@ -858,7 +869,7 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
                 else if(cur < 0)
                 {
                     leaf = cur;
-                    cur  = stack_pop(sp, lds, spill);
+                    cur  = stack_pop<LS>(sp, lds, spill);
                 }
             }
         }
@@ -871,16 +882,16 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
             {
                 ray_prepare<true>(bvh, wo, wtmin, wd, r.tmax, r);
                 inInst = false;
-                cur    = stack_pop(sp, lds, spill);
+                cur    = stack_pop<LS>(sp, lds, spill);
             }
             if(cur < 0 && !inInst)
             {
                 const int32_t root = instance_enter(bvh, cur, wo, wtmin, wd, r.tmax, r, curAbs, primBase);
                 if(root == kEmptyLeaf)
-                    cur = stack_pop(sp, lds, spill);
+                    cur = stack_pop<LS>(sp, lds, spill);
                 else
                 {
-                    stack_push_slow(sp, lds, spill, kInstExit);
+                    stack_push_slow<LS>(sp, lds, spill, kInstExit);
                     inInst = true;
                     cur    = root;
                 }
