@@ -202,6 +202,10 @@ int prt_postprocess(prt_context* ctx, uint8_t* rgba8_out);
 int prt_read_hit_ids(prt_context* ctx, uint32_t* ids_out);
 int prt_get_stats(prt_context* ctx, prt_stats* out); /* synchronous */
 int prt_reset_stats(prt_context* ctx);
+/* Measurement builds only (tools/shade_stamps.py, -DPRT_SHADE_STAMPS): the raw 48 statistics words of the context
+ * (ray counts, node / triangle tallies, wave-step counts, phase time stamps). Synchronous. No counterpart in the
+ * reference. */
+int prt_debug_read_stats(prt_context* ctx, unsigned long long* out48);
 /* The reference has no profiling hooks. level 0: off; 1: bracket every kernel launch with HIP
  * events on the context's stream; 2: additionally run the traversal kernels in their instrumented form that
  * counts node fetches and triangle tests. prt_get_profile is synchronous; totals since prt_reset_stats. */
@@ -226,7 +230,13 @@ int prt_trace_device(prt_context* ctx, const void* rays_dev, size_t n, int any_h
  * memory of the caller). Asynchronous: the launch is enqueued on `stream` (a hipStream_t; NULL = the context's own
  * stream, then prt_sync waits for it) and not timed. n above PRT_NOALLOC_MAX_RAYS is refused with PRT_E_LIMIT.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams or contexts
- * without ordering between them) race on the cursor; serialise them. */
+ * without ordering between them) race on the cursor; serialise them.
+ * The launch carries the acceleration structure by value (array addresses, root, quantisation grid): a launch that was
+ * captured into a graph, or is still in flight on the caller's stream, is INVALIDATED by prt_build_accel,
+ * prt_refit_accel, prt_update_instance_transforms, prt_set_scene, prt_set_instances and prt_destroy. The library cannot
+ * see the caller's stream: order it before those calls (hipStreamSynchronize), and capture again after them. (A refit or
+ * an instance update that does not grow the structure keeps the arrays where they are, so a stale launch reads valid
+ * memory — but with the old grid it decodes the new boxes wrongly: its hits are not to be used.) */
 #define PRT_NOALLOC_MAX_RAYS 0x40000000u /* 2^30 rays per call */
 int prt_trace_device_noalloc(prt_context* ctx, const void* rays_dev, size_t n, int any_hit, void* hits_dev,
                              void* stream);

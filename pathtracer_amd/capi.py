@@ -25,7 +25,7 @@ EXPORTS = [
     "prt_read_hit_ids", "prt_get_stats", "prt_reset_stats", "prt_trace", "prt_trace_device", "prt_trace_device_noalloc", "prt_read_bvh",
     "prt_read_sobol", "prt_set_profiling", "prt_set_profiling_mask", "prt_get_profile", "prt_set_pipeline_depth", "prt_get_pipeline_depth",
     "prt_update_vertices", "prt_refit_accel", "prt_write_accum", "prt_set_iteration_batch", "prt_get_iteration_batch",
-    "prt_set_pass_memory_limit", "prt_get_pass_iterations",
+    "prt_set_pass_memory_limit", "prt_get_pass_iterations", "prt_debug_read_stats",
     "prt_group_create", "prt_group_destroy", "prt_group_last_error", "prt_group_size", "prt_group_uses_rccl",
     "prt_group_context", "prt_group_set_scene", "prt_group_set_scramble_seed", "prt_group_set_uniforms",
     "prt_group_set_flags", "prt_group_clear_accum", "prt_group_render", "prt_group_reduce", "prt_group_read_accum",

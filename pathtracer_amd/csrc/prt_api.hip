@@ -127,6 +127,9 @@ struct prt_context
     std::vector<Tree> blas;
     uint4*     dNodes      = nullptr;  // BVH4, 4 x uint4 per node
     float4*    dTris       = nullptr;
+    size_t     nodesCap = 0, trisCap = 0;  // nodes / 64-byte leaf slots allocated: the arrays stay when a refit fits
+    uint32_t   emittedTopHot = 0xffffffffu;  // two-level: hot nodes the top level had when the bottom level was emitted
+    uint32_t   topColdBase   = 0;            // two-level: where the top level's other nodes start (end of the node array)
     float      buildMs = 0.0f, refitMs = 0.0f;
     // instances (two-level scenes)
     std::vector<prt_blas_range> blasRanges;
@@ -323,6 +326,8 @@ static void free_accel(prt_context* c)
     c->blas.clear();
     dfree(c->dNodes);
     dfree(c->dTris);
+    c->nodesCap = c->trisCap = 0;
+    c->emittedTopHot = 0xffffffffu;
     dfree(c->dInst);
     dfree(c->dShadeInst);
     dfree(c->dInstBase);
@@ -342,6 +347,21 @@ static void free_scene(prt_context* c)
     c->instances.clear();
     c->haveScene = false;
 }
+
+// The traversal kernels exist in four instantiations each, <INSTR, TWO>: with the counters of profiling level 2 or
+// without, for a two-level scene or a single-level one. One table per kernel, indexed [instrumented][two-level]; the
+// resident grid of a two-level variant is gridTwo[...], of a single-level one the kernel's own.
+template <class K>
+struct KernelTable
+{
+    K fn[2][2];
+    K pick(const prt_context* c) const { return fn[c->profLevel >= 2 ? 1 : 0][c->twoLevel() ? 1 : 0]; }
+};
+#define PRT_KERNEL_TABLE(k) {{{k<false, false>, k<false, true>}, {k<true, false>, k<true, true>}}}
+static const KernelTable<decltype(&k_extend<false, false>)>        kExtendTable        = PRT_KERNEL_TABLE(k_extend);
+static const KernelTable<decltype(&k_shadow<false, false>)>        kShadowTable        = PRT_KERNEL_TABLE(k_shadow);
+static const KernelTable<decltype(&k_shadow_extend<false, false>)> kShadowExtendTable  = PRT_KERNEL_TABLE(k_shadow_extend);
+#undef PRT_KERNEL_TABLE
 
 extern "C" {
 
@@ -723,6 +743,32 @@ static prt_host::mat4 to_mat4(const float* m)
     return r;
 }
 
+// kappa = |M|inf * |inverse(M)|inf of the 3 x 3 part (>= 1); false when the transform is singular, not finite or
+// conditioned worse than 1024 (the widening of the top-level box test is bounded with it)
+static bool instance_condition(const float* M, double& kappa)
+{
+    kappa = 1.0;
+    for(int k = 0; k < 16; ++k)
+        if(!std::isfinite(M[k])) { kappa = NAN; return false; }
+    if(is_identity(M)) return true;
+    const prt_host::mat4 W = prt_host::inverse(to_mat4(M));
+    double nM = 0.0, nW = 0.0;
+    bool   finite = true;
+    for(int r = 0; r < 3; ++r)
+    {
+        const double rm = fabs((double)M[0 + r]) + fabs((double)M[4 + r]) + fabs((double)M[8 + r]);
+        const double rw = fabs((double)W[0][r]) + fabs((double)W[1][r]) + fabs((double)W[2][r]);
+        nM = rm > nM ? rm : nM;
+        nW = rw > nW ? rw : nW;
+    }
+    for(int cc = 0; cc < 4; ++cc)
+        for(int rr = 0; rr < 4; ++rr) finite = finite && std::isfinite(W[cc][rr]);
+    kappa = nM * nW;
+    if(!finite || !(kappa == kappa) || kappa > 1024.0) return false;
+    if(kappa < 1.0) kappa = 1.0;
+    return true;
+}
+
 // Top level of a two-level scene: conservative world boxes of the instances (bottom-level root box through the
 // transform, in double, rounded outwards and padded), a tree over them with one instance per leaf.
 static int tlas_build(prt_context* c)
@@ -750,25 +796,8 @@ static int tlas_build(prt_context* c)
         }
         // condition of the linear part (row-sum norms): scales the rounding error of o' = W*o, M*o' - o
         double kappa = 1.0;
-        if(!is_identity(M))
-        {
-            const prt_host::mat4 W = prt_host::inverse(to_mat4(M));
-            double nM = 0.0, nW = 0.0;
-            for(int r = 0; r < 3; ++r)
-            {
-                const double rm = fabs((double)M[0 + r]) + fabs((double)M[4 + r]) + fabs((double)M[8 + r]);
-                const double rw = fabs((double)W[0][r]) + fabs((double)W[1][r]) + fabs((double)W[2][r]);
-                nM = rm > nM ? rm : nM;
-                nW = rw > nW ? rw : nW;
-            }
-            kappa = nM * nW;
-            bool finite = true;
-            for(int cc = 0; cc < 4; ++cc)
-                for(int rr = 0; rr < 4; ++rr) finite = finite && std::isfinite(W[cc][rr]);
-            if(!finite || !(kappa == kappa) || kappa > 1024.0 || !(amax < 1e30))
-                return fail(c, PRT_E_INVALID, "prt_build_accel: the transform of instance %zu is singular or too ill-conditioned (condition %g)", i, kappa);
-            if(kappa < 1.0) kappa = 1.0;
-        }
+        if(!instance_condition(M, kappa) || !(amax < 1e30))
+            return fail(c, PRT_E_INVALID, "prt_build_accel: the transform of instance %zu is singular or too ill-conditioned (condition %g)", i, kappa);
         padScale = kappa * kappa > padScale ? kappa * kappa : padScale;
         const double pad = 16.0 * 5.9604644775390625e-08 * kappa * amax + 1e-30;
         for(int k = 0; k < 3; ++k)
@@ -858,9 +887,36 @@ static int instance_tables(prt_context* c)
     return PRT_OK;
 }
 
+// Node / leaf arrays of at least this size. They are kept when they are large enough, so that a refit or an instance
+// update of unchanged size leaves the device addresses where they were (prt_trace_device_noalloc callers hold them in
+// launches they enqueued themselves; the contents and the quantisation grid still change: see prt.h).
+static hipError_t accel_reserve(prt_context* c, size_t nodes, size_t slots)
+{
+    hipError_t e = hipSuccess;
+    if(nodes > c->nodesCap || !c->dNodes)
+    {
+        dfree(c->dNodes);
+        c->nodesCap = 0;
+        e = dalloc(c->dNodes, (nodes ? nodes : 1) * 4);
+        if(e == hipSuccess) c->nodesCap = nodes ? nodes : 1;
+    }
+    if(e == hipSuccess && (slots > c->trisCap || !c->dTris))
+    {
+        dfree(c->dTris);
+        c->trisCap = 0;
+        e = dalloc(c->dTris, (size_t)PRT_LEAF_SLOT_F4 * (slots ? slots : 1));
+        if(e == hipSuccess) c->trisCap = slots ? slots : 1;
+    }
+    return e;
+}
+
 // Traversal layout of all trees (after a build or a refit of the bottom level): for a two-level scene this (re)builds
 // the top level from the current boxes of the bottom-level structures and the current transforms.
-static int accel_emit(prt_context* c)
+// topOnly (prt_update_instance_transforms, the top level's "updateOnly"): the bottom-level structures have not changed
+// since the last emission, so their nodes and leaf records stay where they are and only the top level (tree, nodes,
+// instance tables) is made again: O(instances), not O(scene). Node array of a two-level scene:
+// [tops of the trees: top level | structures] [the structures' other nodes] [the top level's other nodes].
+static int accel_emit(prt_context* c, bool topOnly = false)
 {
     auto cleanup = [&]() {};
     int  rc;
@@ -870,49 +926,58 @@ static int accel_emit(prt_context* c)
         if(c->top.nInner >= (1u << 26)) return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^26 BVH4 nodes");
         c->top.place = NodePlace{0, 0, 0, 0};
         c->nHot      = c->top.nInner < PRT_TOP_NODES ? c->top.nInner : PRT_TOP_NODES;
-        dfree(c->dNodes);
-        dfree(c->dTris);
-        TCHK(dalloc(c->dNodes, (size_t)(c->top.nInner ? c->top.nInner : 1) * 4));
-        TCHK(dalloc(c->dTris, (size_t)PRT_LEAF_SLOT_F4 * c->top.N));
+        TCHK(accel_reserve(c, c->top.nInner, c->top.N));
         tree_emit(c, c->top, true);
     }
     else
     {
-        for(Tree& t : c->blas)
-            if((rc = tree_layout(c, t))) return rc;
+        bool blasLaidOut = false;
+        if(!topOnly)
+        {
+            // (root boxes of the structures: the top level is built from them)
+            for(Tree& t : c->blas)
+                if((rc = tree_layout(c, t))) return rc;
+            blasLaidOut = true;
+        }
         if((rc = tlas_build(c))) return rc;
         if((rc = tree_layout(c, c->top))) return rc;
         // hot parts first (LDS-staged by the traversal kernels): a third of the budget for the top level, the rest
         // shared by the bottom-level structures when they are few enough to get at least 4 nodes each
         const uint32_t budget = PRT_TOP_NODES;
         const uint32_t kTop   = c->top.nInner < budget / 3 ? c->top.nInner : budget / 3;
-        const uint32_t kBlas  = c->blas.size() * 4 <= budget - kTop ? (uint32_t)((budget - kTop) / c->blas.size()) : 0u;
-        uint64_t       hot = 0, sb = 0;
-        c->top.place = NodePlace{0, kTop, 0, 0};
-        hot += kTop;
-        for(Tree& t : c->blas)
+        const bool     keep   = topOnly && kTop == c->emittedTopHot && c->dNodes && c->dTris;
+        if(!keep)
         {
-            const uint32_t k = t.nInner < kBlas ? t.nInner : kBlas;
-            t.place          = NodePlace{(uint32_t)hot, k, 0, (uint32_t)sb};
-            hot += k;
-            sb += t.N;
+            for(Tree& t : c->blas)
+                if(!blasLaidOut && (rc = tree_layout(c, t))) return rc;
+            const uint32_t kBlas = c->blas.size() * 4 <= budget - kTop ? (uint32_t)((budget - kTop) / c->blas.size()) : 0u;
+            uint64_t       hot = kTop, sb = 0;
+            for(Tree& t : c->blas)
+            {
+                const uint32_t k = t.nInner < kBlas ? t.nInner : kBlas;
+                t.place          = NodePlace{(uint32_t)hot, k, 0, (uint32_t)sb};
+                hot += k;
+                sb += t.N;
+            }
+            uint64_t nb = hot;
+            for(Tree& t : c->blas)
+            {
+                t.place.coldBase = (uint32_t)nb;
+                nb += t.nInner - t.place.hotCount;
+            }
+            c->nHot        = (uint32_t)hot;
+            c->topColdBase = (uint32_t)nb;
+            // the top level's part is sized for the largest tree over this many instances (one leaf each: fewer inner
+            // nodes than instances), so that moving the instances never moves the arrays
+            if(nb + c->instances.size() + 1 >= (1u << 26) || sb >= (1u << 28))
+                return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^26 BVH4 nodes");
+            TCHK(accel_reserve(c, (size_t)nb + c->instances.size() + 1, (size_t)sb));
+            for(Tree& t : c->blas) tree_emit(c, t, true);
+            c->emittedTopHot = kTop;
         }
-        uint64_t nb = hot;
-        c->top.place.coldBase = (uint32_t)nb;
-        nb += c->top.nInner - c->top.place.hotCount;
-        for(Tree& t : c->blas)
-        {
-            t.place.coldBase = (uint32_t)nb;
-            nb += t.nInner - t.place.hotCount;
-        }
-        c->nHot = (uint32_t)hot;
-        if(nb >= (1u << 26) || sb >= (1u << 28)) return fail(c, PRT_E_LIMIT, "prt_build_accel: more than 2^26 BVH4 nodes");
-        dfree(c->dNodes);
-        dfree(c->dTris);
-        TCHK(dalloc(c->dNodes, (size_t)(nb ? nb : 1) * 4));
-        TCHK(dalloc(c->dTris, (size_t)PRT_LEAF_SLOT_F4 * sb));
+        if(c->top.nInner - kTop > c->instances.size() + 1) return fail(c, PRT_E_LIMIT, "prt_build_accel: top level larger than its reserve");
+        c->top.place = NodePlace{0, kTop, c->topColdBase, 0};
         tree_emit(c, c->top, false);
-        for(Tree& t : c->blas) tree_emit(c, t, true);
         TCHK(hipGetLastError());
         TCHK(hipStreamSynchronize(c->stream));
         if((rc = instance_tables(c))) return rc;
@@ -1053,7 +1118,11 @@ int prt_refit_accel(prt_context* c)
         for(Tree& t : c->blas) tree_refit(c, t);  // the top level is rebuilt from the new boxes by accel_emit
     HIPCHK(c, hipGetLastError());
     const int rc = accel_emit(c);
-    if(rc) return rc;
+    if(rc)
+    {
+        c->haveAccel = false;  // the arrays may be partly rewritten or gone: nothing may be traced against them
+        return rc;
+    }
     c->accelStale = false;
     c->refitMs    = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PRT_OK;
@@ -1074,12 +1143,19 @@ int prt_update_instance_transforms(prt_context* c, const float* transforms, size
         if(m[3] != 0.0f || m[7] != 0.0f || m[11] != 0.0f || m[15] != 1.0f)
             return fail(c, PRT_E_INVALID, "prt_update_instance_transforms: instance %zu: the fourth row of the transform must be (0,0,0,1)", i);
     }
+    // nothing is committed before every transform has been checked: a refused update leaves the scene as it was
+    for(size_t i = 0; i < ninst; ++i)
+    {
+        double kappa;
+        if(!instance_condition(transforms + 16 * i, kappa))
+            return fail(c, PRT_E_INVALID, "prt_update_instance_transforms: the transform of instance %zu is singular or too ill-conditioned (condition %g)", i, kappa);
+    }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, sync_all(c));
     for(size_t i = 0; i < ninst; ++i) memcpy(c->instances[i].transform, transforms + 16 * i, 64);
     if(!c->haveAccel) return PRT_OK;
     const auto t0 = std::chrono::steady_clock::now();
-    const int  rc = accel_emit(c);
+    const int  rc = accel_emit(c, !c->accelStale);  // top level only, unless moved vertices await their refit
     if(rc)
     {
         c->haveAccel = false;
@@ -1252,21 +1328,8 @@ static void launch_extend(prt_context* c, hipStream_t st, const SceneView& sc, c
                           uint32_t q /* generation of path state */, const uint32_t* n, uint32_t* work, uint32_t primary)
 {
     ProfScope ps(c, PRT_K_EXTEND, st);
-    if(c->twoLevel())
-    {
-        if(c->profLevel >= 2)
-            hipLaunchKernelGGL((k_extend<true, true>), dim3(c->gridTwo[0]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, q, n, work,
-                               primary, trace_tune());
-        else
-            hipLaunchKernelGGL((k_extend<false, true>), dim3(c->gridTwo[0]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, q, n, work,
-                               primary, trace_tune());
-    }
-    else if(c->profLevel >= 2)
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, q, n, work, primary,
-                           trace_tune());
-    else
-        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, q, n, work, primary,
-                           trace_tune());
+    hipLaunchKernelGGL(kExtendTable.pick(c), dim3(c->twoLevel() ? c->gridTwo[0] : grid), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, q,
+                       n, work, primary, trace_tune());
 }
 
 static int pipe_ensure(prt_context* c, Pipe& p, size_t npass, int B);
@@ -1294,21 +1357,12 @@ static int render_ao(prt_context* c, uint32_t nsub = 1)
     launch_extend(c, st, sc, f, c->gridExtend, 0u, nullptr, p.counters + 0, 1u);
     {
         ProfScope ps(c, PRT_K_AO_SHADE, st);
-        if(c->twoLevel())
-        {
-            if(nsub > 1)
-                hipLaunchKernelGGL((k_ao_shade<true, true>), dim3(c->gridTwo[3]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo,
-                                   c->flags, p.counters + 1);
-            else
-                hipLaunchKernelGGL((k_ao_shade<true, false>), dim3(c->gridTwo[3]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo,
-                                   c->flags, p.counters + 1);
-        }
-        else if(nsub > 1)
-            hipLaunchKernelGGL((k_ao_shade<false, true>), dim3(c->gridAo), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo, c->flags,
-                               p.counters + 1);
-        else
-            hipLaunchKernelGGL((k_ao_shade<false, false>), dim3(c->gridAo), dim3(PRT_TRACE_BLOCK), 0, st, sc, f, c->ubo,
-                               c->flags, p.counters + 1);
+        // k_ao_shade<TWO, BATCH>
+        static const decltype(&k_ao_shade<false, false>) kAo[2][2] = {{k_ao_shade<false, false>, k_ao_shade<false, true>},
+                                                                      {k_ao_shade<true, false>, k_ao_shade<true, true>}};
+        const bool two = c->twoLevel();
+        hipLaunchKernelGGL(kAo[two ? 1 : 0][nsub > 1 ? 1 : 0], dim3(two ? c->gridTwo[3] : c->gridAo), dim3(PRT_TRACE_BLOCK), 0, st,
+                           sc, f, c->ubo, c->flags, p.counters + 1);
     }
     if(nsub > 1)
     {
@@ -1403,58 +1457,22 @@ static int render_path_pass(prt_context* c, int pi, int aa, uint32_t nsub = 1, u
         if(b == 0 || !c->fuse) launch_extend(c, st, sc, f, c->gridExtend, (uint32_t)b, nIn, p.counters + 64 + b, b == 0 ? 1u : 0u);
         {
             ProfScope ps(c, PRT_K_SHADE, st);
-            if(c->twoLevel())
-                hipLaunchKernelGGL(k_shade<true>, dim3(c->gridTwo[5]), dim3(256), 0, st, sc, f, c->ubo, fl, (uint32_t)b, nIn,
-                                   p.counters + b + 1, p.counters + 32 + b);
-            else
-                hipLaunchKernelGGL(k_shade<false>, dim3(gridShade), dim3(256), 0, st, sc, f, c->ubo, fl, (uint32_t)b, nIn,
-                                   p.counters + b + 1, p.counters + 32 + b);
+            const bool two = c->twoLevel();
+            hipLaunchKernelGGL(two ? k_shade<true> : k_shade<false>, dim3(two ? c->gridTwo[5] : gridShade), dim3(256), 0, st, sc, f,
+                               c->ubo, fl, (uint32_t)b, nIn, p.counters + b + 1, p.counters + 32 + b);
         }
         if(c->fuse && b < B)
         {
             ProfScope ps(c, PRT_K_SHADOW_EXTEND, st);
-            if(c->twoLevel())
-            {
-                if(c->profLevel >= 2)
-                    hipLaunchKernelGGL((k_shadow_extend<true, true>), dim3(c->gridTwo[4]), dim3(PRT_TRACE_BLOCK), 0, st, sc,
-                                       f, (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
-                                       (const uint32_t*)(p.counters + b + 1), p.counters + 64 + b + 1, trace_tune());
-                else
-                    hipLaunchKernelGGL((k_shadow_extend<false, true>), dim3(c->gridTwo[4]), dim3(PRT_TRACE_BLOCK), 0, st, sc,
-                                       f, (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
-                                       (const uint32_t*)(p.counters + b + 1), p.counters + 64 + b + 1, trace_tune());
-            }
-            else if(c->profLevel >= 2)
-                hipLaunchKernelGGL(k_shadow_extend<true>, dim3(c->gridFused), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                                   (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
-                                   (const uint32_t*)(p.counters + b + 1), p.counters + 64 + b + 1, trace_tune());
-            else
-                hipLaunchKernelGGL(k_shadow_extend<false>, dim3(c->gridFused), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                                   (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
-                                   (const uint32_t*)(p.counters + b + 1), p.counters + 64 + b + 1, trace_tune());
+            hipLaunchKernelGGL(kShadowExtendTable.pick(c), dim3(c->twoLevel() ? c->gridTwo[4] : c->gridFused), dim3(PRT_TRACE_BLOCK),
+                               0, st, sc, f, (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
+                               (const uint32_t*)(p.counters + b + 1), p.counters + 64 + b + 1, trace_tune());
         }
         else
         {
             ProfScope ps(c, PRT_K_SHADOW, st);
-            if(c->twoLevel())
-            {
-                if(c->profLevel >= 2)
-                    hipLaunchKernelGGL((k_shadow<true, true>), dim3(c->gridTwo[1]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                                       (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
-                                       trace_tune());
-                else
-                    hipLaunchKernelGGL((k_shadow<false, true>), dim3(c->gridTwo[1]), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                                       (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b,
-                                       trace_tune());
-            }
-            else if(c->profLevel >= 2)
-                hipLaunchKernelGGL(k_shadow<true>, dim3(c->gridShadow), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                                   (const uint32_t*)(p.counters + 32 + b),
-                                   p.counters + 128 + b, (uint32_t)b, trace_tune());
-            else
-                hipLaunchKernelGGL(k_shadow<false>, dim3(c->gridShadow), dim3(PRT_TRACE_BLOCK), 0, st, sc, f,
-                                   (const uint32_t*)(p.counters + 32 + b),
-                                   p.counters + 128 + b, (uint32_t)b, trace_tune());
+            hipLaunchKernelGGL(kShadowTable.pick(c), dim3(c->twoLevel() ? c->gridTwo[1] : c->gridShadow), dim3(PRT_TRACE_BLOCK), 0,
+                               st, sc, f, (const uint32_t*)(p.counters + 32 + b), p.counters + 128 + b, (uint32_t)b, trace_tune());
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -1783,21 +1801,12 @@ int prt_get_profile(prt_context* c, prt_profile* out)
 static void launch_trace_batch(prt_context* c, hipStream_t st, const BvhView& bvh, const void* rays, size_t n, int any,
                                void* hits, uint32_t* work)
 {
-    if(c->twoLevel())
-    {
-        if(any)
-            hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(c->gridTwo[2]), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
-                               (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
-        else
-            hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(c->gridTwo[2]), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
-                               (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
-    }
-    else if(any)
-        hipLaunchKernelGGL(k_trace_batch<true>, dim3(c->gridBatch), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
-                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
-    else
-        hipLaunchKernelGGL(k_trace_batch<false>, dim3(c->gridBatch), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
-                           (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
+    // k_trace_batch<ANY, TWO>
+    static const decltype(&k_trace_batch<false, false>) kBatch[2][2] = {{k_trace_batch<false, false>, k_trace_batch<false, true>},
+                                                                        {k_trace_batch<true, false>, k_trace_batch<true, true>}};
+    const bool two = c->twoLevel();
+    hipLaunchKernelGGL(kBatch[any ? 1 : 0][two ? 1 : 0], dim3(two ? c->gridTwo[2] : c->gridBatch), dim3(PRT_TRACE_BLOCK), 0, st, bvh,
+                       (const float4*)rays, (uint32_t)n, (float4*)hits, work, trace_tune(), c->stats);
 }
 
 int prt_trace_device(prt_context* c, const void* rays, size_t n, int any, void* hits, float* ms)

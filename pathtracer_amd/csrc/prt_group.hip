@@ -340,6 +340,7 @@ int prt_group_get_stats(prt_group* g, prt_stats* out)
         if(rc) return gfail(g, rc, "prt_group_get_stats: member %zu: %s", i, prt_last_error(g->ctx[i]));
         out->rays += s.rays;
         out->iterations += s.iterations;
+        out->trace_overruns = s.trace_overruns > 0xffffffffu - out->trace_overruns ? 0xffffffffu : out->trace_overruns + s.trace_overruns;
         if(i == 0)
         {
             out->bvh_nodes       = s.bvh_nodes;

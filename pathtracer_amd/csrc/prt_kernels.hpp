@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(256) k_gather_shading(const prt_vertex* __rest
 #define PRT_SHADE_WAVES_TWO 4  // two-level scenes (2: 20.3 ms, 4: 19.3 ms per pass)
 #endif
 #ifndef PRT_SHADE_WAVES
-#define PRT_SHADE_WAVES 4  // 128 VGPRs, no scratch; 5 or 6 spill and are slower, 2-3 leave the compiler 132 VGPRs = 3 waves per SIMD
+#define PRT_SHADE_WAVES 4  // 117 VGPRs, no scratch (tools/kernel_resources.py); 5 or 6 spill and are no faster, 2-3 leave the compiler 132 VGPRs = 3 waves per SIMD
 #endif
 template <bool TWO = false>
 __global__ void __launch_bounds__(256, TWO ? PRT_SHADE_WAVES_TWO : PRT_SHADE_WAVES) k_shade(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,

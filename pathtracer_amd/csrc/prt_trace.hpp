@@ -6,12 +6,14 @@
 //   row of four child references. The traversal kernels are bound by the vector-memory pipeline
 //   (TA/TCP: random 16-byte requests), not by VALU or HBM, so bytes and loads per visit are what counts;
 //   the de-quantisation folds into the per-ray slab constants: t = fma(float(q), r*scale, c').
-// * Leaves reference runs of <= 2 pre-gathered triangles, 48 bytes each (3 x float4, prim id in
-//   v0.w), packed into ONE aligned 128-byte record per leaf (what a divergent gather costs is the number of
-//   128-byte lines it touches: tools/ubench_gather.hip).
+// * Leaves reference runs of <= 2 pre-gathered triangles in 64-byte slots (one sector: what a divergent gather costs
+//   is the number of sectors it touches, tools/ubench_gather.hip): a single triangle is 3 x float4 (prim id in v0.w), two
+//   triangles that form a fan (A, B, C), (A, C, D) — 9 leaves in 10 — are their four corners in ONE slot, any other pair
+//   takes two slots (leaf_test).
 // * Per-lane traversal stack: the first PRT_LDS_STACK entries live in LDS, laid out [entry][lane] so
 //   that a wave's push/pop is one conflict-free ds_write_b32/ds_read_b32; deeper entries (rare)
-//   spill to scratch.
+//   spill to scratch. The same LDS words hold the part of a ray's state that the node steps never touch (tag, best hit's
+//   prim / u / v): with 9 slab constants per ray that is what lets the kernels run at 7 waves per SIMD (72 VGPRs).
 // * trace_stream(): persistent waves. A wave keeps up to 64 rays in flight; lanes whose ray has
 //   finished are refilled from the queue (chunked work fetch, one atomic per PRT_CHUNK rays), node
 //   steps and triangle tests run in separate wave-uniform phases (a found leaf is postponed while the
@@ -21,8 +23,8 @@
 //   functions that evaluate to exactly 0; two-sided triangles (TRIANGLE_CULL_DISABLE,
 //   vkRT_TLAS.cpp:218-223); hit iff tmin < t < tmax; closest hit ties -> lower primitive id.
 //   The result of a trace is therefore independent of the tree and of the traversal order; the box
-//   test only has to be conservative: boxes grown by 64*2^-24*max(|origin|, |scene|), slab distances
-//   widened by 2^-21 (covers v_rcp_f32 + the fma rounding).
+//   test only has to be conservative: boxes grown by 64*2^-24*max(|origin|, |scene|), which covers v_rcp_f32, the
+//   roundings of the slab arithmetic and the tolerance of the triangle test (budget in ray_prepare).
 // * Two-level scenes (instances of bottom-level structures, vkRT_TLAS.cpp:58-72): the TWO instantiations of
 //   trace_ray / trace_stream walk a top-level BVH4 over the instances' world boxes in the same node array; a lane
 //   that reaches an instance takes its ray to object space (same t), pushes an exit marker and walks the
@@ -693,7 +695,7 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, const uint4* top, f3 o,
 // IO::store(tag, hit) is called once per ray when it has finished.
 // TWO: two-level scene. A lane at the top level that reaches a leaf (= an instance) enters it at the next node step;
 // a lane that pops the exit marker leaves the instance once its postponed leaf (which belongs to the instance) has
-// been tested. The world-space ray stays in six registers (the TWO kernels run at 4 waves per SIMD and have them).
+// been tested. The world-space ray stays in seven registers (the TWO kernels are compiled for 6 waves per SIMD, 80 VGPRs, and have them).
 template <bool ANY, bool INSTR, class IO, bool TWO = false>
 PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, uint32_t count, uint32_t* workCtr,
                           const TraceTune tune, IO& io, uint32_t& nskipped, TraceCount& tc)

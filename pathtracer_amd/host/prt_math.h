@@ -3,6 +3,22 @@
 // order, so that the 464-byte parameter block comes out bit-identical (checked against values produced by
 // glm itself: tests/golden/host_golden.json).
 //   column-major mat4: m[col][row], as glm and GLSL.
+//
+// perspectiveRH_ZO, lookAtRH and inverse(mat4) below restate, term for term (that is the point: same roundings), the
+// formulas of OpenGL Mathematics (GLM) 0.9.9.5 — ext/matrix_clip_space.inl, ext/matrix_transform.inl,
+// detail/func_matrix.inl (compute_inverse<4, 4>). GLM is Copyright (c) 2005 - G-Truc Creation and distributed under
+// the MIT License:
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files (the "Software"), to deal in the Software without restriction, including without limitation
+//   the rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and
+//   to permit persons to whom the Software is furnished to do so, subject to the following conditions:
+//   The above copyright notice and this permission notice shall be included in all copies or substantial portions of
+//   the Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO
+//   THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN NO EVENT SHALL THE
+//   AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF
+//   CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS
+//   IN THE SOFTWARE.
 #pragma once
 #include <cmath>
 

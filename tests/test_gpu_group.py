@@ -86,6 +86,7 @@ def test_group_with_instances_equals_single_context():
     c.render(capi.MODE_PATH, 1, 6)
     whole = c.read_accum()
     assert g.stats().rays == c.stats().rays
+    assert g.stats().trace_overruns == 0 and c.stats().trace_overruns == 0
     c.close()
     g.close()
     assert np.allclose(got, whole, rtol=3e-6, atol=1e-6) and (got[..., 3] == whole[..., 3]).all()

@@ -187,6 +187,43 @@ def test_instance_transform_update_equals_fresh_build(po):
     ctx.close()
 
 
+def test_refused_transform_update_leaves_the_scene_as_it_was(po):
+    """prt_update_instance_transforms checks every transform before it commits any: after a refused update (singular,
+    not finite) the context still traces the old placements. Several updates in a row (the top level is rebuilt each
+    time, the bottom-level structures' nodes and leaf records stay) end where a fresh build of the last one ends,
+    also when the top level shrinks and grows between them."""
+    sc = scenes.instanced_scene(seed=23, n_instances=30, wild=True)
+    o, ctx = _pair(po, sc, 16, 16)
+    rays = _rays(20000, 8)
+    before = ctx.trace(rays).tobytes()
+    assert before == o.trace_closest(rays, brute=True).tobytes()
+    for bad_value in (scenes.affine(scale=(1.0, 0.0, 1.0)), np.full(16, np.nan, np.float32)):
+        t = sc["instances"]["transform"].copy()
+        t[7] = np.asarray(bad_value, np.float32).reshape(-1)
+        if np.isnan(t[7]).any():
+            t[7][[3, 7, 11]] = 0.0
+            t[7][15] = 1.0  # a legal fourth row, so that the finiteness check is what refuses it
+        with pytest.raises(capi.PrtError):
+            ctx.update_instance_transforms(t)
+        assert ctx.trace(rays).tobytes() == before
+    # far apart -> all in one spot -> the placements of another scene: top-level trees of different sizes
+    spread = sc["instances"]["transform"].copy()
+    for i in range(len(spread)):
+        spread[i] = np.asarray(scenes.affine(translate=(7.0 * i, 0.0, -3.0 * i)), np.float32).reshape(-1)
+    heap = sc["instances"]["transform"].copy()
+    heap[:] = heap[0]
+    sc2 = scenes.instanced_scene(seed=24, n_instances=30, wild=True)
+    for t in (spread, heap, sc2["instances"]["transform"]):
+        ctx.update_instance_transforms(t)
+        inst = sc["instances"].copy()
+        inst["transform"] = t
+        o2 = po.Oracle(sc, seed=3)
+        o2.set_instances(sc["blas"], inst)
+        assert ctx.trace(rays).tobytes() == o2.trace_closest(rays, brute=True).tobytes()
+    assert ctx.stats().trace_overruns == 0
+    ctx.close()
+
+
 def test_refit_of_an_instanced_scene(po):
     sc = scenes.instanced_scene(seed=21, n_instances=10)
     o, ctx = _pair(po, sc, 16, 16)
