@@ -1832,7 +1832,7 @@ float orc_gamma(float x)
     const float n = floorf(y + 0.5f);
     const float t = (y - n) * 0.693147181f;
     const float q = ((((((t * 1.98412698e-4f + 1.38888889e-3f) * t + 8.33333333e-3f) * t + 4.16666667e-2f) * t + 0.166666667f) * t + 0.5f) * t + 1.0f) * t + 1.0f;
-    return bits_float(float_bits(q) + ((int)n << 23));
+    return bits_float(float_bits(q) + (int)n * (1 << 23));  // (not "<< 23": n may be negative)
 }
 
 // The shading helpers one by one, for the identity tests (unit tier) and for the transcription audit

@@ -362,7 +362,7 @@ PRT_DEV float gamma_fixed(float x)
     const float n = __builtin_floorf(y + 0.5f);
     const float t = (y - n) * 0.693147181f;
     const float q = ((((((t * 1.98412698e-4f + 1.38888889e-3f) * t + 8.33333333e-3f) * t + 4.16666667e-2f) * t + 0.166666667f) * t + 0.5f) * t + 1.0f) * t + 1.0f;
-    return __int_as_float(__float_as_int(q) + ((int)n << 23));
+    return __int_as_float(__float_as_int(q) + (int)n * (1 << 23));  // (not "<< 23": n may be negative)
 }
 
 // Bilinear / REPEAT fetch of an RGBA8 UNORM texture (sampler of vkTools.cpp:456-480), fp32 weights.
