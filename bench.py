@@ -76,6 +76,35 @@ def host_threads():
     return max(1, n)
 
 
+def load_obj_scene(path, camera=None):
+    """A real asset through the host layer's Model (libprt_host: prth_model_load = Model::LoadModelFromFile,
+    src/Model.cpp:47-221, with its textures; the reference hard-codes the path, src/vkContext.cpp:52-72). `camera` =
+    "ex,ey,ez,tx,ty,tz"; default: inside the bounding box, a quarter of its extent from the centre, looking at the centre.
+    As in the reference at start-up the light sits at the camera and faces where it looks (m_moveLight,
+    vkContext.cpp:1008-1017)."""
+    from pathtracer_amd import hostapi
+
+    scene = hostapi.load_model(path)
+    if len(scene["indices"]) == 0:
+        raise SystemExit(f"bench.py: {path} holds no triangles")
+    p = scene["vertices"]["p"]
+    p = p[np.isfinite(p).all(axis=1)]
+    lo, hi = p.min(axis=0).astype(np.float64), p.max(axis=0).astype(np.float64)
+    if camera:
+        c = [float(x) for x in camera.split(",")]
+        if len(c) != 6:
+            raise SystemExit("--camera wants ex,ey,ez,tx,ty,tz")
+        eye, target = np.array(c[:3]), np.array(c[3:])
+    else:
+        target = (lo + hi) / 2
+        eye = target + (hi - lo) * np.array([-0.25, 0.1, 0.22])
+    fwd = (target - eye) / max(1e-30, np.linalg.norm(target - eye))
+    scene["camera"] = {"eye": eye.astype(np.float32), "target": target.astype(np.float32)}
+    scene["light"] = {"pos": eye.astype(np.float32), "dir": fwd.astype(np.float32)}
+    scene["name"] = os.path.basename(path)
+    return scene
+
+
 def self_launch(n, argv):
     """`python3 bench.py --gpus N` without a launcher: start N ranks, one process per GPU, exactly as the driver's
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...` form would. This parent has made
@@ -120,6 +149,12 @@ def main():
     ap.add_argument("--scene", default="conference", choices=["conference", "sponza", "sanmiguel"],
                     help="conference = the metric's workload (default); the others are BASELINE.json configs[3], [4]")
     ap.add_argument("--rr", action="store_true", help="Russian roulette (configs[3])")
+    ap.add_argument("--obj", default="", help="render this OBJ file (+ its MTL and textures, loaded by libprt_host's Model) "
+                                              "instead of a procedural stand-in: the real conference / Sponza / San Miguel "
+                                              "assets when they are supplied (SURVEY.md 8d)")
+    ap.add_argument("--camera", default="", help="with --obj: ex,ey,ez,tx,ty,tz (default: inside the bounding box)")
+    ap.add_argument("--light-area", type=float, default=0.0, help="half-extent of the area light (default 0.02 = the "
+                                                                  "reference's UI default; 0.5 for the large stand-ins)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample")
@@ -174,13 +209,16 @@ def main():
 
     W, H, K, WU = args.width, args.height, args.steps, args.warmup
     t0 = time.time()
-    if args.scene == "conference":
+    if args.obj:
+        scene = load_obj_scene(args.obj, args.camera)
+        args.scene = scene["name"]
+    elif args.scene == "conference":
         scene = scenes.conference_room(seed=2, detail=args.detail)
     elif args.scene == "sponza":
         scene = scenes.sponza_scale(seed=4)
     else:
         scene = scenes.san_miguel_scale(seed=5, million_tris=10.0)
-    light_area = 0.02 if args.scene == "conference" else 0.5
+    light_area = args.light_area or (0.02 if (args.scene == "conference" or args.obj) else 0.5)
     ntri = len(scene["indices"]) // 3
     ctx = capi.Context(W, H, device=local)
     ctx.set_scene(scene)
@@ -190,7 +228,8 @@ def main():
     if rank == 0:
         log(f"[bench] scene {scene['name']}: {ntri} triangles, BVH {st.bvh_nodes} nodes depth {st.bvh_depth} "
             f"built on GPU in {st.bvh_build_ms:.1f} ms (setup {time.time() - t0:.1f} s)")
-    workload = (f"{scene['name']} ({args.scene}-scale), {ntri} triangles, {W}x{H}, path tracing, {args.bounces} bounces"
+    what = f"OBJ file {scene['name']}" if args.obj else f"{scene['name']} ({args.scene}-scale)"
+    workload = (f"{what}, {ntri} triangles, {W}x{H}, path tracing, {args.bounces} bounces"
                 f"{' + Russian roulette' if args.rr else ''}, GGX + area-light NEE, 1 spp per step")
     ubo = uniforms.make_uniforms(scene, W, H, bounces=args.bounces, spp=1024, iteration=1, light_area=light_area)
     ctx.set_uniforms(ubo)
@@ -413,7 +452,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": f"synthetic (procedural {args.scene}-scale scene; the reference's scenes are not in its repo)",
+            "data": (f"OBJ asset {args.obj} loaded through libprt_host (Model)" if args.obj else
+                     f"synthetic (procedural {args.scene}-scale scene; the reference's scenes are not in its repo)"),
             "config": {"workload": workload,
                        "triangles": ntri, "width": W, "height": H, "bounces": args.bounces,
                        "iterations_per_gpu": K, "parallelism": f"spp-sharded x{n_gpus}" if n_gpus > 1 else "single GPU",

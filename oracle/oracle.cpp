@@ -1892,6 +1892,16 @@ int orc_helper(int which, const float* in, float* out)
     }
 }
 
+// texture(textureSamplers[id], uv).xyz as the oracle defines it (textureRGB above): for the transcription audit
+void orc_texture_rgb(const orc_scene* s, int id, float u, float v, float* rgb_out)
+{
+    vec3 c = V3(1.0f);
+    if(s && id >= 0 && (size_t)id < s->tex.size()) c = textureRGB(s->tex[(size_t)id], vec2{u, v});
+    rgb_out[0] = c.x;
+    rgb_out[1] = c.y;
+    rgb_out[2] = c.z;
+}
+
 // pathRTpostprocess.comp:38-51
 void orc_postprocess(const float* accum, uint32_t w, uint32_t h, uint8_t* out)
 {

@@ -102,6 +102,8 @@ uint64_t orc_render(const orc_scene*, const prt_uniforms* ubo, uint32_t w, uint3
 
 /* pathRTpostprocess.comp:38-51 over the full image. out = RGBA8. */
 void orc_postprocess(const float* accum, uint32_t w, uint32_t h, uint8_t* rgba8_out);
+/* texture(textureSamplers[id], uv).xyz: bilinear, REPEAT, RGBA8 UNORM (vkTools.cpp:405,456-480); white for a bad id */
+void orc_texture_rgb(const orc_scene*, int id, float u, float v, float* rgb_out);
 float orc_gamma(float x);
 /* the shading helpers of pathRT.rgen one at a time (identity tests, transcription audit); returns the number of floats
  * written to `out`, -1 for an unknown `which` */

@@ -297,3 +297,39 @@ def test_cli_aa_uses_the_frame_loops_stride(po, tmp_path):
         ref = acc[..., :3] / acc[..., 3:4]
     ok = np.isfinite(ref).all(axis=-1) & np.isfinite(img).all(axis=-1)
     assert ok.mean() > 0.5 and np.allclose(img[ok], ref[ok], rtol=0, atol=0)
+
+
+def test_bench_renders_an_obj_file(po, tmp_path):
+    """`bench.py --obj PATH`: a real asset goes through libprt_host's Model (OBJ + MTL + textures) into the HIP path; the
+    line names the file, and the image of the timed region is the oracle's for the same scene and uniforms, bit for bit."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    from pathtracer_amd import capi, uniforms
+
+    obj = os.path.join(root, "tests", "golden", "obj", "mixed.obj")
+    W, H, K = 96, 64, 3
+    out = tmp_path / "img.npy"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--obj", obj, "--width", str(W), "--height", str(H),
+                          "--steps", str(K), "--warmup", "1", "--bounces", "4", "--no-cpu-baseline", "--dump-accum", str(out)],
+                         cwd=root, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert "mixed.obj" in line["metric"] and "mixed.obj" in line["config"]["workload"] and "libprt_host" in line["data"]
+    assert line["config"]["triangles"] == 16 and line["roofline"]["traffic"] is None  # no counters for this workload
+    sc = bench.load_obj_scene(obj)
+    assert len(sc["textures"]) == 5
+    o = po.Oracle(sc, seed=2)
+    acc, rays = np.zeros((H, W, 4), np.float32), 0
+    for it in range(1, K + 1):
+        u = uniforms.make_uniforms(sc, W, H, bounces=4, spp=1024, iteration=it, light_area=0.02)
+        acc, _, r = o.render(u, W, H, capi.MODE_PATH, accum=acc)
+        rays += r
+    got = np.load(out)
+    assert line["config"]["rays_total"] == rays
+    assert got.tobytes() == acc.tobytes()
