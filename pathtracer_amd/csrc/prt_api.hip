@@ -402,7 +402,11 @@ int prt_create(int device, uint32_t width, uint32_t height, prt_context** out)
         c->gridFused  = resident((const void*)k_shadow_extend<false>);
         // k_shade strides over its queue with a fixed stride: every block must be resident from the start, or the
         // late blocks do their whole share on a nearly empty GPU
-        c->gridShade  = resident((const void*)k_shade<false>);
+        {
+            int nb = 0;
+            if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_shade<false>, PRT_SHADE_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+            c->gridShade = (uint32_t)nb * (uint32_t)c->numCU;
+        }
         if(const char* g = getenv("PRT_SHADE_BLOCKS_PER_CU"))
         {
             const int nb = atoi(g);
@@ -1066,7 +1070,11 @@ int prt_build_accel(prt_context* c)
         c->gridTwo[2] = resident((const void*)k_trace_batch<false, true>);
         c->gridTwo[3] = resident((const void*)k_ao_shade<true>);
         c->gridTwo[4] = resident((const void*)k_shadow_extend<false, true>);
-        c->gridTwo[5] = resident((const void*)k_shade<true>);
+        {
+            int nb = 0;
+            if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_shade<true>, PRT_SHADE_BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
+            c->gridTwo[5] = (uint32_t)nb * (uint32_t)c->numCU;
+        }
     }
     return PRT_OK;
 }
@@ -1458,7 +1466,7 @@ static int render_path_pass(prt_context* c, int pi, int aa, uint32_t nsub = 1, u
         {
             ProfScope ps(c, PRT_K_SHADE, st);
             const bool two = c->twoLevel();
-            hipLaunchKernelGGL(two ? k_shade<true> : k_shade<false>, dim3(two ? c->gridTwo[5] : gridShade), dim3(256), 0, st, sc, f,
+            hipLaunchKernelGGL(two ? k_shade<true> : k_shade<false>, dim3(two ? c->gridTwo[5] : gridShade), dim3(PRT_SHADE_BLOCK), 0, st, sc, f,
                                c->ubo, fl, (uint32_t)b, nIn, p.counters + b + 1, p.counters + 32 + b);
         }
         if(c->fuse && b < B)

@@ -134,7 +134,16 @@ struct PushTicket
     unsigned long long mask;
     uint32_t           base;  // thread 0 only
 };
-PRT_DEV PushTicket block_push_begin(bool pred, uint32_t* counter, uint32_t* lds /*[8]*/)
+#ifndef PRT_SHADE_BLOCK
+// Threads per block of k_shade = path vertices per pair of queue atomics (the compaction is block-wide: one atomicAdd on
+// the shadow queue's length and one on the next generation's per trip). Those two words are what bounded the kernel at
+// 256 threads: 1.04 M same-address atomics per launch of 132.7 M slots = 111 per microsecond and word, beyond the ~88
+// a word sustains (MI355X_MICROARCH.md, dequeue). Measured per launch (bench, 64 iterations per pass): 128 threads
+// 8.66 ms, 256: 4.67, 512: 4.39, 1024: 4.63 (one block per CU: the barriers span the CU).
+#define PRT_SHADE_BLOCK 512
+#endif
+#define PRT_SHADE_NW (PRT_SHADE_BLOCK / 64)
+PRT_DEV PushTicket block_push_begin(bool pred, uint32_t* counter, uint32_t* lds /*[2 * PRT_SHADE_NW]*/)
 {
     PushTicket t;
     t.mask = __ballot(pred);
@@ -144,8 +153,13 @@ PRT_DEV PushTicket block_push_begin(bool pred, uint32_t* counter, uint32_t* lds 
     __syncthreads();
     if(threadIdx.x == 0)
     {
-        const uint32_t tot = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+        uint32_t tot = 0;
+        for(int w = 0; w < PRT_SHADE_NW; ++w) tot += lds[w];
+#ifdef PRT_FAKE_PUSH  // timing builds only (wrong queues): what k_shade costs without the same-address atomics
+        t.base = blockIdx.x * PRT_SHADE_BLOCK;
+#else
         if(tot) t.base = atomicAdd(counter, tot);
+#endif
     }
     return t;
 }
@@ -154,17 +168,18 @@ PRT_DEV void block_push_publish(const PushTicket& t, uint32_t* lds)
 {
     if(threadIdx.x == 0)
     {
-        const uint32_t n0 = lds[0], n1 = lds[1], n2 = lds[2];
-        lds[4] = t.base;
-        lds[5] = t.base + n0;
-        lds[6] = t.base + n0 + n1;
-        lds[7] = t.base + n0 + n1 + n2;
+        uint32_t run = t.base;
+        for(int w = 0; w < PRT_SHADE_NW; ++w)
+        {
+            lds[PRT_SHADE_NW + w] = run;
+            run += lds[w];
+        }
     }
 }
 PRT_DEV uint32_t block_push_slot(const PushTicket& t, const uint32_t* lds)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    return lds[4 + wid] + (uint32_t)__popcll(t.mask & ((1ull << lane) - 1ull));
+    return lds[PRT_SHADE_NW + wid] + (uint32_t)__popcll(t.mask & ((1ull << lane) - 1ull));
 }
 
 PRT_DEV uint32_t wave_fetch(uint32_t* workCtr, uint32_t n)
@@ -436,7 +451,7 @@ __global__ void __launch_bounds__(256) k_gather_shading(const prt_vertex* __rest
 #define PRT_SHADE_WAVES 4  // 117 VGPRs, no scratch (tools/kernel_resources.py); 5 or 6 spill and are no faster, 2-3 leave the compiler 132 VGPRs = 3 waves per SIMD
 #endif
 template <bool TWO = false>
-__global__ void __launch_bounds__(256, TWO ? PRT_SHADE_WAVES_TWO : PRT_SHADE_WAVES) k_shade(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,
+__global__ void __launch_bounds__(PRT_SHADE_BLOCK, TWO ? PRT_SHADE_WAVES_TWO : PRT_SHADE_WAVES) k_shade(SceneView sc, FrameView f, const prt_uniforms ubo_, uint32_t flags,
                                                uint32_t bounce, const uint32_t* __restrict__ countIn,
                                                uint32_t* countNext, uint32_t* countShadow)
 {
@@ -446,7 +461,7 @@ __global__ void __launch_bounds__(256, TWO ? PRT_SHADE_WAVES_TWO : PRT_SHADE_WAV
     __shared__ uint32_t sobT[5 * 1024];
     {
         const uint32_t dim0 = 4u + 4u * bounce, dimR = 48u + bounce + 1u;
-        for(uint32_t k = threadIdx.x; k < 5u * 1024u; k += 256u)
+        for(uint32_t k = threadIdx.x; k < 5u * 1024u; k += PRT_SHADE_BLOCK)
         {
             const uint32_t d = k >> 10;
             const uint32_t g = d < 4u ? dim0 + d : dimR;
@@ -455,7 +470,7 @@ __global__ void __launch_bounds__(256, TWO ? PRT_SHADE_WAVES_TWO : PRT_SHADE_WAV
         __syncthreads();
     }
     const uint32_t count      = countIn ? *countIn : f.npix;
-    __shared__ uint32_t pushLds[2][2][8];  // [trip parity][shadow | next]: a trip's slots are read while the next trip counts
+    __shared__ uint32_t pushLds[2][2][2 * PRT_SHADE_NW];  // [trip parity][shadow | next]: a trip's slots are read while the next trip counts
     const bool     literal    = (flags & PRT_FLAG_LITERAL) != 0;
     const bool     rr         = (flags & PRT_FLAG_RUSSIAN_ROULETTE) != 0;
     const int      maxBounces = ubo->numIndirectBounces;
@@ -500,9 +515,9 @@ __global__ void __launch_bounds__(256, TWO ? PRT_SHADE_WAVES_TWO : PRT_SHADE_WAV
         }
         return st;
     };
-    SlotState nx     = load_state(blockIdx.x * 256u + threadIdx.x);
+    SlotState nx     = load_state(blockIdx.x * PRT_SHADE_BLOCK + threadIdx.x);
     uint32_t  parity = 0;
-    for(uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u, parity ^= 1u)  // block-uniform trip count
+    for(uint32_t base = blockIdx.x * PRT_SHADE_BLOCK; base < count; base += gridDim.x * PRT_SHADE_BLOCK, parity ^= 1u)  // block-uniform trip count
     {
 #ifdef PRT_SHADE_STAMPS
         unsigned long long stampMark = __builtin_amdgcn_s_memtime();
@@ -750,7 +765,7 @@ __global__ void __launch_bounds__(256, TWO ? PRT_SHADE_WAVES_TWO : PRT_SHADE_WAV
         }
         PRT_STAMP(3)  // stores, termination
         const PushTicket tNext = block_push_begin(nextQ, countNext, pushLds[parity][1]);
-        nx = load_state(i + gridDim.x * 256u);
+        nx = load_state(i + gridDim.x * PRT_SHADE_BLOCK);
         block_push_publish(tShadow, pushLds[parity][0]);
         block_push_publish(tNext, pushLds[parity][1]);
         __syncthreads();
@@ -779,7 +794,7 @@ __global__ void __launch_bounds__(256, TWO ? PRT_SHADE_WAVES_TWO : PRT_SHADE_WAV
 #ifdef PRT_SHADE_STAMPS
     if((threadIdx.x & 63) == 0)
         for(int k = 0; k < 6; ++k) atomicAdd(f.stats + 36 + k, stampT[k]);
-    if(threadIdx.x == 0) atomicAdd(f.stats + 42, (unsigned long long)((count + 255u) / 256u > blockIdx.x ? ((count + 255u) / 256u - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u));
+    if(threadIdx.x == 0) atomicAdd(f.stats + 42, (unsigned long long)((count + PRT_SHADE_BLOCK - 1u) / PRT_SHADE_BLOCK > blockIdx.x ? ((count + PRT_SHADE_BLOCK - 1u) / PRT_SHADE_BLOCK - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u));
 #endif
 #undef PRT_STAMP
 }
