@@ -719,6 +719,11 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
             {
                 qmn[k][j] = quant_floor(fdec(c.bmin[k]), g.qmin[k], g.qscale[k]);
                 qmx[k][j] = quant_ceil(fdec(c.bmax[k]), g.qmin[k], g.qscale[k]);
+#ifdef PRT_QUANT_COARSE  // measurement builds: what boxes on a 2^(16 - PRT_QUANT_COARSE) grid cost in node visits
+                qmn[k][j] = (qmn[k][j] >> PRT_QUANT_COARSE) << PRT_QUANT_COARSE;
+                qmx[k][j] = ((qmx[k][j] + (1u << PRT_QUANT_COARSE) - 1u) >> PRT_QUANT_COARSE) << PRT_QUANT_COARSE;
+                if(qmx[k][j] > 65535u) qmx[k][j] = 65535u;
+#endif
             }
             bool swap;
             ref[j] = c.count == 0 ? (int32_t)node_place(pl, wideIdx[slot[j]])
