@@ -365,18 +365,19 @@ def main():
 
             allk = json.load(open(pmc))
             ent = allk.get("scenes", {}).get(args.scene)
-            if allk.get("kernel_source_hash") != kernel_source_hash():
-                src = (f"none: profiles/pmc_traffic.json was measured on kernel sources {allk.get('kernel_source_hash')}, this "
-                       f"tree is {kernel_source_hash()} (re-run tools/profile.sh + tools/summarize_profile.py)")
-            elif ent is None or ent.get("workload") != workload:
+            if ent is None or ent.get("workload") != workload:
                 src = (f"none: profiles/pmc_traffic.json holds no counters for this workload ({workload!r}); it has "
                        f"{sorted(allk.get('scenes', {}))}")
+            elif ent.get("kernel_source_hash") != kernel_source_hash():
+                src = (f"none: the counters of scenes[{args.scene!r}] were measured on kernel sources "
+                       f"{ent.get('kernel_source_hash')}, this tree is {kernel_source_hash()} (re-run tools/profile.sh + "
+                       f"tools/summarize_profile.py)")
             else:
                 t = ent["kernels"].get(kname.split(" ")[0], {})
                 if t.get("hbm_bytes_per_ray"):
                     traffic = int(t["hbm_bytes_per_ray"] * n1)
                     src = (f"profiles/pmc_traffic.json scenes[{args.scene!r}] [{ent.get('tag', '?')}, kernel sources "
-                           f"{allk['kernel_source_hash']}]: (FETCH_SIZE x {t.get('fetch_correction', 2)} + WRITE_SIZE) "
+                           f"{ent['kernel_source_hash']}]: (FETCH_SIZE x {t.get('fetch_correction', 2)} + WRITE_SIZE) "
                            f"per ray = {t['hbm_bytes_per_ray']} B at {t.get('rays_per_launch')} rays per launch, scaled to this run's "
                            f"{n1:.0f} rays per launch; counted at the L2's fabric side, so Infinity-Cache hits are included "
                            f"(upper bound on HBM bytes)")

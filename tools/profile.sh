@@ -14,6 +14,7 @@ T=${PROFILE_TIMEOUT:-300}
 cd $ROOT
 rm -rf $OUT; mkdir -p $OUT
 echo "$ARGS" > $OUT/command.txt
+python3 -c "from pathtracer_amd.buildinfo import kernel_source_hash as h; print(h())" > $OUT/kernel_source_hash.txt
 echo "== kernel trace"; timeout -s KILL $T rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $ARGS > $OUT/trace.json 2> $OUT/trace.log || exit 1
 echo "== pmc FETCH_SIZE"; timeout -s KILL $T rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python3 $ARGS > /dev/null 2> $OUT/fetch.log || exit 1
 echo "== pmc WRITE_SIZE"; timeout -s KILL $T rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- python3 $ARGS > /dev/null 2> $OUT/write.log || exit 1

@@ -22,6 +22,11 @@ G = os.path.join(ROOT, "gpurun_out", f"prof_{name}")
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 command = open(os.path.join(G, "command.txt")).read().strip() if os.path.exists(os.path.join(G, "command.txt")) else "?"
+# the kernel sources the counters were taken on (written by tools/profile.sh on the GPU box)
+run_hash = open(os.path.join(G, "kernel_source_hash.txt")).read().strip() if os.path.exists(os.path.join(G, "kernel_source_hash.txt")) else None
+if run_hash != kernel_source_hash():
+    print(f"WARNING: gpurun_out/prof_{name} was measured on kernel sources {run_hash}, this tree is {kernel_source_hash()}: "
+          f"the entry is stamped {run_hash} and bench.py will not use it")
 bench = None
 try:
     bench = json.loads([l for l in open(os.path.join(G, "trace.json")) if l.startswith("{")][-1])
@@ -166,6 +171,7 @@ if bench and bench.get("roofline"):
             f"{e.get('valu_busy_simd')}, a wave waits {e['wait_any_per_wave_cycle']:.2f} of its life: "
             + ("latency-bound on L2 / Infinity-Cache gathers, not HBM-bound" if e["hbm_frac_of_8TB/s"] < 0.5 else "HBM-bandwidth-bound"))
 entry = {"workload": (bench or {}).get("config", {}).get("workload"), "command": command, "tag": tag,
+         "kernel_source_hash": run_hash,
          "iterations_per_pass": (bench or {}).get("config", {}).get("iterations_per_pass"), "kernels": traffic}
 pj = os.path.join(P, "pmc_traffic.json")
 allj = {}
@@ -174,11 +180,12 @@ if os.path.exists(pj):
         allj = json.load(open(pj))
     except Exception:  # noqa: BLE001
         allj = {}
-if "scenes" not in allj or allj.get("kernel_source_hash") != kernel_source_hash():
-    allj = {"kernel_source_hash": kernel_source_hash(), "scenes": {}}  # counters of other sources are not carried over
+if "scenes" not in allj:
+    allj = {"scenes": {}}
+allj.pop("kernel_source_hash", None)  # (round 3a files carried one stamp for all scenes)
 allj["scenes"][name] = entry
 json.dump(allj, open(pj, "w"), indent=1)
-out.append(f"\n## Derived per kernel (profiles/pmc_traffic.json, scenes[{name!r}], kernel sources {kernel_source_hash()})\n")
+out.append(f"\n## Derived per kernel (profiles/pmc_traffic.json, scenes[{name!r}], kernel sources {run_hash})\n")
 out.append("```\n" + json.dumps(entry, indent=1) + "\n```")
 open(os.path.join(P, f"{tag}_{name}_rocprof_summary.md"), "w").write("\n".join(out) + "\n")
 if bench:
