@@ -8,10 +8,10 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 
 
 def kernel_source_hash():
-    """sha256 over csrc/*.hpp, *.hip and the Makefile (names and bytes, sorted), first 16 hex digits."""
+    """sha256 over csrc/*.hpp (every kernel lives there) and the Makefile (the compiler flags), names and bytes,
+    sorted; first 16 hex digits. The .hip files hold host code only (the C-ABI, launch sequences)."""
     h = hashlib.sha256()
-    for p in sorted(glob.glob(os.path.join(_CSRC, "*.hpp")) + glob.glob(os.path.join(_CSRC, "*.hip")) +
-                    [os.path.join(_CSRC, "Makefile")]):
+    for p in sorted(glob.glob(os.path.join(_CSRC, "*.hpp")) + [os.path.join(_CSRC, "Makefile")]):
         h.update(os.path.basename(p).encode())
         h.update(open(p, "rb").read())
     return h.hexdigest()[:16]

@@ -128,6 +128,7 @@ struct prt_context
     uint4*     dNodes      = nullptr;  // BVH4, 4 x uint4 per node
     float4*    dTris       = nullptr;
     size_t     nodesCap = 0, trisCap = 0;  // nodes / 64-byte leaf slots allocated: the arrays stay when a refit fits
+    size_t     instCap = 0, instBaseCap = 0;  // float4 of dInst (dShadeInst has as many) / words of dInstBase allocated
     uint32_t   emittedTopHot = 0xffffffffu;  // two-level: hot nodes the top level had when the bottom level was emitted
     uint32_t   topColdBase   = 0;            // two-level: where the top level's other nodes start (end of the node array)
     float      buildMs = 0.0f, refitMs = 0.0f;
@@ -331,6 +332,7 @@ static void free_accel(prt_context* c)
     dfree(c->dInst);
     dfree(c->dShadeInst);
     dfree(c->dInstBase);
+    c->instCap = c->instBaseCap = 0;
     c->haveAccel = false;
 }
 static void free_scene(prt_context* c)
@@ -879,12 +881,23 @@ static int instance_tables(prt_context* c)
         base[n + 1 + k] = (uint32_t)i;
     }
     c->instShift = shift;
-    dfree(c->dInst);
-    dfree(c->dShadeInst);
-    dfree(c->dInstBase);
-    HIPCHK(c, dalloc(c->dInst, trav.size()));
-    HIPCHK(c, dalloc(c->dShadeInst, shade.size()));
-    HIPCHK(c, dalloc(c->dInstBase, base.size()));
+    // the tables stay where they are while they are large enough (an instance update of unchanged size moves nothing)
+    if(trav.size() > c->instCap || !c->dInst || !c->dShadeInst)
+    {
+        dfree(c->dInst);
+        dfree(c->dShadeInst);
+        c->instCap = 0;
+        HIPCHK(c, dalloc(c->dInst, trav.size()));
+        HIPCHK(c, dalloc(c->dShadeInst, shade.size()));
+        c->instCap = trav.size();
+    }
+    if(base.size() > c->instBaseCap || !c->dInstBase)
+    {
+        dfree(c->dInstBase);
+        c->instBaseCap = 0;
+        HIPCHK(c, dalloc(c->dInstBase, base.size()));
+        c->instBaseCap = base.size();
+    }
     HIPCHK(c, hipMemcpy(c->dInst, trav.data(), trav.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->dShadeInst, shade.data(), shade.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->dInstBase, base.data(), base.size() * 4, hipMemcpyHostToDevice));
