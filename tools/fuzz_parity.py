@@ -1,4 +1,5 @@
-"""Randomised GPU-vs-oracle parity: random soups / rooms, sizes, bounces, flags, batches, pipeline depths.
+"""Randomised GPU-vs-oracle parity: random soups / rooms, sizes, bounces, flags, batches, pipeline depths, pass-memory
+limits, and a second render after the scene moved (instance placements / vertex jitter + refit).
 usage: python tools/fuzz_parity.py [seconds] [seed] [big]   -- prints one line per case, exits 1 at the first difference."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -60,32 +61,46 @@ while time.time() - t0 < budget:
                     open(os.environ["FUZZ_DUMP_SCENE"], "wb"))
         print("dumped", desc)
         sys.exit(0)
-    o = po.Oracle(sc, seed=seed)
-    if "instances" in sc:
-        o.set_instances(sc["blas"], sc["instances"])
-    o.build_bvh()
+    table = None
+    if rng.random() < 0.2:  # the reference's explicit 32-layer scramble image instead of the hash
+        table = rng.integers(0, 2 ** 32, (32, H * W), dtype=np.uint64).astype(np.uint32)
+
+    def make_oracle(scene):
+        o = po.Oracle(scene, seed=seed)
+        if "instances" in scene:
+            o.set_instances(scene["blas"], scene["instances"])
+        o.build_bvh()
+        if table is not None:
+            o.set_scramble_table(table, W, H)
+        return o
+
+    def compare(ctx, o):
+        ctx.clear_accum(); ctx.reset_stats()
+        ctx.render(mode, first, n, stride)
+        acc, ids, rays = np.zeros((H, W, 4), np.float32), None, 0
+        for k in range(n):
+            acc, ids, r = o.render(uniforms.make_uniforms(sc, W, H, iteration=first + k * stride, **kw), W, H, mode, accum=acc,
+                                   flags=flags, want_ids=True)
+            rays += r
+        g = ctx.read_accum()
+        nd = int((g.view(np.uint32) != acc.view(np.uint32)).any(axis=-1).sum())
+        gids, st = ctx.read_hit_ids(), ctx.stats()
+        return (nd == 0 and (gids == ids).all() and st.rays == rays and st.trace_overruns == 0), nd, g, acc, gids, ids, st.rays, rays
+
+    o = make_oracle(sc)
     ctx = capi.Context(W, H)
     ctx.set_scene(sc)
     if "instances" in sc:
         ctx.set_instances(sc["blas"], sc["instances"])
     ctx.set_seed(seed); ctx.build_accel(); ctx.set_flags(flags)
     ctx.set_pipeline_depth(depth); ctx.set_iteration_batch(batch)
-    if rng.random() < 0.2:  # the reference's explicit 32-layer scramble image instead of the hash
-        table = rng.integers(0, 2 ** 32, (32, H * W), dtype=np.uint64).astype(np.uint32)
+    if rng.random() < 0.25:  # memory policy: a limit that lets only part of the batch through
+        ctx.set_pass_memory_limit(int(W * H * (218 + 16 * kw["bounces"]) * rng.uniform(0.5, batch)))
+        desc += " limited"
+    if table is not None:
         ctx.upload_scrambles(table)
-        o.set_scramble_table(table, W, H)
     ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, **kw))
-    ctx.reset_stats()
-    ctx.render(mode, first, n, stride)
-    acc, ids, rays = np.zeros((H, W, 4), np.float32), None, 0
-    for k in range(n):
-        acc, ids, r = o.render(uniforms.make_uniforms(sc, W, H, iteration=first + k * stride, **kw), W, H, mode, accum=acc,
-                               flags=flags, want_ids=True)
-        rays += r
-    g = ctx.read_accum()
-    nd = int((g.view(np.uint32) != acc.view(np.uint32)).any(axis=-1).sum())
-    gids, grays = ctx.read_hit_ids(), ctx.stats().rays
-    ok = nd == 0 and (gids == ids).all() and grays == rays
+    ok, nd, g, acc, gids, ids, grays, rays = compare(ctx, o)
     if "instances" in sc:  # random rays against the oracle's brute force over all instances
         nr = 20000
         arr = np.zeros(nr, capi.RAY_DTYPE)
@@ -93,6 +108,27 @@ while time.time() - t0 < budget:
         arr["tmin"], arr["tmax"] = 1e-6, rng.choice([0.5, 2.0, 1e3], nr)
         ok = ok and ctx.trace(arr).tobytes() == o.trace_closest(arr, brute=True).tobytes()
         ok = ok and ((ctx.trace(arr, any_hit=True)["prim"] != 0xFFFFFFFF) == o.trace_any(arr, brute=True).astype(bool)).all()
+    if ok and rng.random() < 0.4:
+        # the scene moves: instances get new placements (top level rebuilt) or the vertices are jittered (refit);
+        # the same context renders again and must equal the oracle on the moved scene
+        if "instances" in sc:
+            inst = sc["instances"].copy()
+            for i in range(len(inst)):
+                # column-major storage: the flat arrays are the transposes, (D * M)^T = M^T * D^T
+                d = scenes.affine(translate=tuple(rng.normal(0, 0.5, 3)), axis=tuple(rng.normal(0, 1, 3) + 1e-3),
+                                  angle=float(rng.uniform(-1, 1)), scale=float(rng.uniform(0.7, 1.4))).reshape(4, 4)
+                inst["transform"][i] = (inst["transform"][i].reshape(4, 4) @ d).astype(np.float32).reshape(-1)
+            sc = dict(sc, instances=inst)
+            ctx.update_instance_transforms(inst["transform"])
+            desc += " +moved"
+        else:
+            v = sc["vertices"].copy()
+            v["p"] += rng.normal(0, 0.01 * float(np.abs(v["p"]).max()) * rng.uniform(0, 1), v["p"].shape).astype(np.float32)
+            sc = dict(sc, vertices=v)
+            ctx.update_vertices(v); ctx.refit_accel()
+            desc += " +refit"
+        o = make_oracle(sc)
+        ok, nd, g, acc, gids, ids, grays, rays = compare(ctx, o)
     if not ok and os.environ.get("FUZZ_DEBUG"):
         # one iteration at a time: which iteration, which pixels, how many rays
         for k in range(n):
