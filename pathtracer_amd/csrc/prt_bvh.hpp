@@ -783,9 +783,10 @@ __global__ void __launch_bounds__(256) k_emit_leaves(const BuildNode* __restrict
         const float*   a = verts[idx[3 * p]].p;
         const float*   b = verts[idx[3 * p + 1]].p;
         const float*   c = verts[idx[3 * p + 2]].p;
-        o[3 * q]         = make_float4(a[0], a[1], a[2], __int_as_float((int)p));
-        o[3 * q + 1]     = make_float4(b[0], b[1], b[2], 0.0f);
-        o[3 * q + 2]     = make_float4(c[0], c[1], c[2], 0.0f);
+        float4*        w = o + (PRT_LEAF_SPLIT_PAIR ? PRT_LEAF_SLOT_F4 : 3) * q;  // split pairs: one triangle per slot
+        w[0]             = make_float4(a[0], a[1], a[2], __int_as_float((int)p));
+        w[1]             = make_float4(b[0], b[1], b[2], 0.0f);
+        w[2]             = make_float4(c[0], c[1], c[2], 0.0f);
     }
 }
 // float view of the build nodes for prt_read_bvh()

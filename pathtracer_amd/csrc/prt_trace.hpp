@@ -58,6 +58,19 @@ namespace prt {
 #define PRT_LEAF_QUAD 1
 #endif
 #endif
+// A pair of triangles that is no fan takes two slots. 1: a leaf test handles the first one and hands back a reference to
+// the second (a single-triangle leaf in the next slot), which the lane keeps as its postponed leaf for a later triangle
+// round — no dependent second fetch inside the round that every lane of the wave would wait for.
+#ifndef PRT_LEAF_SPLIT_PAIR
+#if PRT_LEAF_QUAD
+#define PRT_LEAF_SPLIT_PAIR 1  // k_shadow_extend 12.85 -> 12.55 ms per launch (profiles/r03_exp_split_pair.log)
+#else
+#define PRT_LEAF_SPLIT_PAIR 0
+#endif
+#endif
+#if PRT_LEAF_SPLIT_PAIR && !PRT_LEAF_QUAD
+#error "PRT_LEAF_SPLIT_PAIR needs the one-slot leaf forms of PRT_LEAF_QUAD"
+#endif
 #define PRT_SPILL_STACK (100 - PRT_LDS_STACK)
 #define PRT_MAX_DEPTH 64  // depth limit of the binary build tree (=> <= 33 BVH4 levels, <= 100 stack entries)
 #ifndef PRT_TRACE_BLOCK
@@ -492,10 +505,11 @@ PRT_DEV bool leaf_hit(Hit& best, uint32_t* lds, float tt, float uu, float vv, ui
     return false;
 }
 template <bool ANY, bool INSTR, bool COLD = false>
-PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit& best, TraceCount& tc, float sceneAbs,
+PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t& leafRef, Hit& best, TraceCount& tc, float sceneAbs,
                        uint32_t primBase, uint32_t* lds = nullptr)
 {
     const uint32_t ref   = ~(uint32_t)leafRef;
+    leafRef              = kEmptyLeaf;  // what is left of the leaf after this call (PRT_LEAF_SPLIT_PAIR)
     const uint32_t first = ref >> 3, count = ref & 7u;
     if(count == 0) return false;
     const float4* t = bvh.tris + (size_t)first * PRT_LEAF_SLOT_F4;  // the leaf's first 64-byte slot (k_emit_leaves)
@@ -516,6 +530,16 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
         if(tri_core(r, sceneAbs, A, B, C, U0, V0, W0, tt, uu, vv))
             if(leaf_hit<ANY, COLD>(best, lds, tt, uu, vv, primBase + (uint32_t)__float_as_int(qa.w))) return true;
         if(count == 1u) return false;
+#if PRT_LEAF_SPLIT_PAIR
+        if(count == 2u)
+        {
+            leafRef = (int32_t) ~(((first + 1u) << 3) | 1u);
+            return false;
+        }
+        const TriVtx   A1 = A, B1 = C, C1 = tri_vertex(r, kx, ky, qd);
+        const float    W1  = -V0;
+        const uint32_t id1 = (uint32_t)__float_as_int(qb.w);
+#else
         TriVtx   A1, B1, C1;
         float    W1;
         uint32_t id1;
@@ -536,6 +560,7 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t leafRef, Hit
             W1  = B1.x * A1.y - B1.y * A1.x;
             id1 = (uint32_t)__float_as_int(qd.w);
         }
+#endif
         const float U1 = C1.x * B1.y - C1.y * B1.x;
         const float V1 = A1.x * C1.y - A1.y * C1.x;
         if(INSTR) tc.tris++;
@@ -679,7 +704,7 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, const uint4* top, f3 o,
         else
         {
             if(leaf_test<ANY, INSTR>(bvh, r, cur, best, tc, TWO ? curAbs : bvh.sceneAbs, TWO ? primBase : 0u)) break;
-            cur = stack_pop<LS>(sp, lds, spill);
+            if(cur == kEmptyLeaf) cur = stack_pop<LS>(sp, lds, spill);  // else: the rest of the leaf
         }
     }
     if(INSTR && tcp)
@@ -846,6 +871,7 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
                 // the wave runs as many sequential tests as its largest leaf; lTri counts the tests that did work
                 uint32_t cnt = has ? (~(uint32_t)leaf & 7u) : 0u;
                 if(PRT_LEAF_QUAD && cnt == 3u) cnt = 2u;
+                if(PRT_LEAF_SPLIT_PAIR && cnt == 2u && (~(uint32_t)leaf & 7u) == 2u) cnt = 1u;
                 uint32_t       tot = cnt, mx = cnt;
                 for(int o = 32; o > 0; o >>= 1)
                 {
@@ -862,13 +888,13 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
             if(has)
             {
                 const bool occluded = leaf_test<ANY, INSTR, true>(bvh, r, leaf, best, tc, TWO ? curAbs : bvh.sceneAbs, TWO ? primBase : 0u, lds);
-                leaf                = kEmptyLeaf;
                 if(ANY && occluded)
                 {
-                    cur = kSentinel;
-                    sp  = 1;
+                    leaf = kEmptyLeaf;
+                    cur  = kSentinel;
+                    sp   = 1;
                 }
-                else if(cur < 0)
+                else if(leaf == kEmptyLeaf && cur < 0)
                 {
                     leaf = cur;
                     cur  = stack_pop<LS>(sp, lds, spill);
