@@ -697,6 +697,7 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= nnodes || nodes[i].count != 0 || (level_of(lt, i) & 1u) != 0u) return;
     uint32_t slot[4];
+    int      tri[4] = {-1, -1, -1, -1};  // >= 0: this triangle of the leaf alone (a split pair, below)
     int      n = 0;
     for(uint32_t c = nodes[i].first; c < nodes[i].first + 2; ++c)
     {
@@ -708,6 +709,22 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
         else
             slot[n++] = c;
     }
+#if PRT_LEAF_SPLIT_PAIR
+    // A free child slot takes one half of a pair of triangles that is no fan: two single-triangle leaves with their own
+    // boxes instead of one leaf that needs two fetches (every triangle has its own 64-byte slot, k_emit_leaves).
+    if(verts)
+        for(int j = 0, n0 = n; j < n0 && n < 4; ++j)
+        {
+            const BuildNode c = nodes[slot[j]];
+            bool            swap;
+            if(c.count == 2u && leaf_code(verts, idx, order, c.first, c.count, swap) == 2u)
+            {
+                tri[j]    = 0;
+                slot[n]   = slot[j];
+                tri[n++]  = 1;
+            }
+        }
+#endif
     uint32_t qmn[3][4], qmx[3][4];
     int32_t  ref[4];
     for(int j = 0; j < 4; ++j)
@@ -715,10 +732,26 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
         if(j < n)
         {
             const BuildNode c = nodes[slot[j]];
+            float           lo[3], hi[3];
             for(int k = 0; k < 3; ++k)
             {
-                qmn[k][j] = quant_floor(fdec(c.bmin[k]), g.qmin[k], g.qscale[k]);
-                qmx[k][j] = quant_ceil(fdec(c.bmax[k]), g.qmin[k], g.qscale[k]);
+                lo[k] = fdec(c.bmin[k]);
+                hi[k] = fdec(c.bmax[k]);
+            }
+            if(tri[j] >= 0)
+            {
+                const uint32_t p = order[c.first + (uint32_t)tri[j]];
+                for(int k = 0; k < 3; ++k)
+                {
+                    const float a = verts[idx[3 * p]].p[k], b = verts[idx[3 * p + 1]].p[k], d = verts[idx[3 * p + 2]].p[k];
+                    lo[k]         = fminf(a, fminf(b, d));
+                    hi[k]         = fmaxf(a, fmaxf(b, d));
+                }
+            }
+            for(int k = 0; k < 3; ++k)
+            {
+                qmn[k][j] = quant_floor(lo[k], g.qmin[k], g.qscale[k]);
+                qmx[k][j] = quant_ceil(hi[k], g.qmin[k], g.qscale[k]);
 #ifdef PRT_QUANT_COARSE  // measurement builds: what boxes on a 2^(16 - PRT_QUANT_COARSE) grid cost in node visits
                 qmn[k][j] = (qmn[k][j] >> PRT_QUANT_COARSE) << PRT_QUANT_COARSE;
                 qmx[k][j] = ((qmx[k][j] + (1u << PRT_QUANT_COARSE) - 1u) >> PRT_QUANT_COARSE) << PRT_QUANT_COARSE;
@@ -726,8 +759,11 @@ __global__ void __launch_bounds__(256) k_emit_wide(const BuildNode* __restrict__
 #endif
             }
             bool swap;
-            ref[j] = c.count == 0 ? (int32_t)node_place(pl, wideIdx[slot[j]])
-                                  : (int32_t)~(((c.first + pl.slotBase) << 3) | leaf_code(verts, idx, order, c.first, c.count, swap));
+            if(tri[j] >= 0)
+                ref[j] = (int32_t) ~(((c.first + (uint32_t)tri[j] + pl.slotBase) << 3) | 1u);
+            else
+                ref[j] = c.count == 0 ? (int32_t)node_place(pl, wideIdx[slot[j]])
+                                      : (int32_t)~(((c.first + pl.slotBase) << 3) | leaf_code(verts, idx, order, c.first, c.count, swap));
         }
         else
         {

@@ -530,7 +530,8 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t& leafRef, Hi
         if(tri_core(r, sceneAbs, A, B, C, U0, V0, W0, tt, uu, vv))
             if(leaf_hit<ANY, COLD>(best, lds, tt, uu, vv, primBase + (uint32_t)__float_as_int(qa.w))) return true;
         if(count == 1u) return false;
-#if PRT_LEAF_SPLIT_PAIR
+#if PRT_LEAF_SPLIT_PAIR == 1
+        // every ray hands the second triangle of a plain pair back
         if(count == 2u)
         {
             leafRef = (int32_t) ~(((first + 1u) << 3) | 1u);
@@ -540,6 +541,13 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t& leafRef, Hi
         const float    W1  = -V0;
         const uint32_t id1 = (uint32_t)__float_as_int(qb.w);
 #else
+        // 2: any-hit rays only — a closest-hit ray wants the second triangle now (a nearer hit culls what it visits next),
+        // an any-hit ray only wants an occluder; 3: every ray, with the code of the unsplit form behind it (measurement)
+        if((PRT_LEAF_SPLIT_PAIR == 3 || (PRT_LEAF_SPLIT_PAIR == 2 && ANY)) && count == 2u)
+        {
+            leafRef = (int32_t) ~(((first + 1u) << 3) | 1u);
+            return false;
+        }
         TriVtx   A1, B1, C1;
         float    W1;
         uint32_t id1;
@@ -553,12 +561,14 @@ PRT_DEV bool leaf_test(const BvhView& bvh, const RayCtx& r, int32_t& leafRef, Hi
         }
         else
         {
-            const float4 qe = t[4], qf = t[5];
-            A1  = tri_vertex(r, kx, ky, qd);
-            B1  = tri_vertex(r, kx, ky, qe);
-            C1  = tri_vertex(r, kx, ky, qf);
+            // the second triangle of a plain pair: packed behind the first one, or in a slot of its own (k_emit_leaves)
+            const float4* t2 = t + (PRT_LEAF_SPLIT_PAIR ? PRT_LEAF_SLOT_F4 : 3);
+            const float4  qe = t2[0], qf = t2[1], qg = t2[2];
+            A1  = tri_vertex(r, kx, ky, qe);
+            B1  = tri_vertex(r, kx, ky, qf);
+            C1  = tri_vertex(r, kx, ky, qg);
             W1  = B1.x * A1.y - B1.y * A1.x;
-            id1 = (uint32_t)__float_as_int(qd.w);
+            id1 = (uint32_t)__float_as_int(qe.w);
         }
 #endif
         const float U1 = C1.x * B1.y - C1.y * B1.x;
@@ -871,7 +881,7 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
                 // the wave runs as many sequential tests as its largest leaf; lTri counts the tests that did work
                 uint32_t cnt = has ? (~(uint32_t)leaf & 7u) : 0u;
                 if(PRT_LEAF_QUAD && cnt == 3u) cnt = 2u;
-                if(PRT_LEAF_SPLIT_PAIR && cnt == 2u && (~(uint32_t)leaf & 7u) == 2u) cnt = 1u;
+                if((PRT_LEAF_SPLIT_PAIR == 1 || PRT_LEAF_SPLIT_PAIR == 3 || (PRT_LEAF_SPLIT_PAIR == 2 && ANY)) && cnt == 2u && (~(uint32_t)leaf & 7u) == 2u) cnt = 1u;
                 uint32_t       tot = cnt, mx = cnt;
                 for(int o = 32; o > 0; o >>= 1)
                 {

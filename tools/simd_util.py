@@ -4,7 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pathtracer_amd import capi, scenes, uniforms
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-sc = scenes.conference_room(seed=2, detail=1.4)
+which = sys.argv[4] if len(sys.argv) > 4 else "conference"  # the bench scenes (bench.py make_scene)
+sc = {"conference": lambda: scenes.conference_room(seed=2, detail=1.4), "sponza": lambda: scenes.sponza_scale(),
+      "sanmiguel": lambda: scenes.san_miguel_scale()}[which]()
 ctx = capi.Context(W, H); ctx.set_scene(sc); ctx.set_seed(2); ctx.build_accel()
 ctx.set_uniforms(uniforms.make_uniforms(sc, W, H, bounces=B, iteration=1))
 ctx.set_profiling(2); ctx.reset_stats(); ctx.render(0, 1, 2, 1)
