@@ -1940,6 +1940,15 @@ int prt_read_blas_bvh(prt_context* c, uint32_t k, prt_bvh_node* nodes, uint32_t*
 }
 
 // measurement builds (-DPRT_SHADE_STAMPS): the raw statistics words
+#ifdef PRT_TIMELINE
+// measurement builds only (tools/timeline.py): the per-wave time stamps of the last traversal stream that ran
+int prt_debug_read_timeline(prt_context* c, unsigned long long* out, unsigned nwords)
+{
+    if(!c || !out || nwords > 8192u * 4u) return PRT_E_INVALID;
+    if(hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return PRT_E_HIP;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)nwords * 8) == hipSuccess ? PRT_OK : PRT_E_HIP;
+}
+#endif
 int prt_debug_read_stats(prt_context* c, unsigned long long* out48)
 {
     if(!c || !out48) return PRT_E_INVALID;

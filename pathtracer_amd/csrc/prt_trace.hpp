@@ -725,6 +725,11 @@ PRT_DEV Hit trace_ray(const BvhView& bvh, uint32_t* lds, const uint4* top, f3 o,
     return best;
 }
 
+#ifdef PRT_TIMELINE
+// measurement builds (tools/timeline.py): per wave of the grid, wall-clock ticks (100 MHz) at the start of its last stream, when it
+// found the queue empty, when it left, and the rays it traced
+static __device__ unsigned long long g_timeline[8192 * 4];
+#endif
 // ---- persistent wave: a stream of `count` rays ----------------------------------------------------------
 // IO::load(i, o, tmin, d, tmax, tag) -> bool (false: a placeholder that does not count in the statistics);
 // IO::store(tag, hit) is called once per ray when it has finished.
@@ -757,6 +762,11 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
     r.tmin = r.tmax = 0.0f;
     PRT_STACK_AT(lds, 0) = (uint32_t)kSentinel;  // bottom of the lane's stack; sp >= 1 always
 
+#ifdef PRT_TIMELINE
+    const unsigned long long tl0 = wall_clock64();
+    unsigned long long       tlE = 0;
+    uint32_t                 tlRays = 0;
+#endif
     unsigned long long tStart = 0, tMark = 0;
     if(INSTR) tStart = tMark = __builtin_amdgcn_s_memtime();
 #define PRT_LAP(field)                                                  \
@@ -786,6 +796,9 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
                 chunkPos = b < count ? b : count;
                 chunkEnd = (count - chunkPos) < PRT_CHUNK ? count : chunkPos + PRT_CHUNK;
                 if(chunkPos == chunkEnd) exhausted = true;
+#ifdef PRT_TIMELINE
+                if(exhausted) tlE = wall_clock64();
+#endif
             }
             const uint32_t avail = chunkEnd - chunkPos;
             const uint32_t take  = nIdle < avail ? nIdle : avail;
@@ -822,6 +835,9 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
             }
             nskip += (uint32_t)__popcll(__ballot(!counted));
             chunkPos += take;
+#ifdef PRT_TIMELINE
+            tlRays += take;
+#endif
         }
         const uint32_t nActive = (uint32_t)__popcll(__ballot(active));
         PRT_LAP(cSetup)
@@ -949,6 +965,16 @@ PRT_DEV void trace_stream(const BvhView& bvh, uint32_t* lds, const uint4* top, u
         }
         PRT_LAP(cTri)
     }
+#ifdef PRT_TIMELINE
+    if(lane == 0)
+    {
+        const uint32_t w = (blockIdx.x * (PRT_TRACE_BLOCK / 64u) + (threadIdx.x >> 6)) & 8191u;
+        g_timeline[w * 4 + 0] = tl0;
+        g_timeline[w * 4 + 1] = tlE;
+        g_timeline[w * 4 + 2] = wall_clock64();
+        g_timeline[w * 4 + 3] = tlRays;
+    }
+#endif
     if(lane == 0) nskipped += nskip;  // the callers sum it over the wave
     if(overrun) tc.overrun = 1u;
     if(INSTR) tc.cTotal += (uint32_t)(__builtin_amdgcn_s_memtime() - tStart);
